@@ -1,0 +1,123 @@
+/*
+ * include/lanczos_hip.h -- C ABI of the MI355X (gfx950) Lanczos-a resampler.
+ *
+ * This is the drop-in boundary for the reference's resample path.  Plain pointers and sizes only;
+ * no C++/torch types.  What each entry point replaces in /root/reference/LanczosUpscaler:
+ *
+ *   lanczos_resample_host / lanczos_u8     <- void lanczos(stream_t, stream_t)   lanczos.h:121-126,
+ *                                             lanczos.cpp:86-98 (called at full_TB.h:140); results are
+ *                                             those of the software model lanczos_expected(),
+ *                                             full_TB.h:79-96, on the stb interleaved layout of
+ *                                             full_TB.h:107 (R | G<<8 | B<<16, worker.cpp:35-43)
+ *   lanczos_resample_device                <- the same, for callers that already hold device memory
+ *                                             (batches of frames, row strips of one frame)
+ *   lanczos_kernel / lanczos_kernel_idx    <- double lanczos_kernel(double)      full_TB.h:51-53 and
+ *                                             kernel_t lanczos_kernel(input_idx_t, output_idx_t, scale_t)
+ *                                             kernel.h:6, kernel.cpp:61-67
+ *   lanczos_desc                           <- the compile-time macros of params.h (lanczos.h:9-31):
+ *                                             IN_WIDTH, IN_HEIGHT, OUT_WIDTH, OUT_HEIGHT, NUM_CHANNELS,
+ *                                             LANCZOS_A, SCALE_N, SCALE_D -- here run-time arguments
+ *   error codes                            <- the EXIT_FAILURE checks of full_TB.h:110-123
+ *
+ * Semantics (all verified against the reference's compiled software path, tests/):
+ *   horizontal pass then vertical pass; taps floor(x)-a+1 .. floor(x)+a with x = out/((double)N/D);
+ *   out-of-range taps dropped, no renormalisation; every store clamps to [0,max] and TRUNCATES; the
+ *   horizontal result is stored as a truncated integer before the vertical pass; the vertical pass is
+ *   IN PLACE bottom-to-top, so the first K output rows read already-written output rows
+ *   (full_TB.h:67-77; K = lanczos_inplace_rows()).
+ */
+#ifndef LANCZOS_HIP_H
+#define LANCZOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LANCZOS_OK 0
+#define LANCZOS_ERR_BAD_ARG 1      /* null pointer, non-positive size, out != in*N/D, a or channels unsupported */
+#define LANCZOS_ERR_UNSUPPORTED 2  /* valid request this build cannot run (scale <= 1, in-place prefix too deep) */
+#define LANCZOS_ERR_NO_DEVICE 3    /* no HIP device / device index out of range */
+#define LANCZOS_ERR_HIP 4          /* a HIP runtime call failed; see lanczos_last_hip_error() */
+#define LANCZOS_ERR_NOMEM 5
+
+/* parity modes (lanczos_desc.mode) */
+#define LANCZOS_MODE_LSB1 0   /* default: horizontal pass bit-exact, vertical pass f32 accumulators;
+                                 every output sample within +-1 LSB of the reference software path */
+#define LANCZOS_MODE_EXACT 1  /* every output sample bit-identical to the reference software path */
+
+/* which kernel family served the last call (lanczos_last_kernel) */
+#define LANCZOS_KERNEL_NONE 0
+#define LANCZOS_KERNEL_GENERIC 1  /* table-driven, any rational scale > 1, f64 throughout (always exact) */
+#define LANCZOS_KERNEL_FAST 2     /* specialised: integer scale, LDS-staged tiles, f32 taps + exact fallback */
+
+typedef struct lanczos_ctx lanczos_ctx; /* opaque: device, stream, cached tap tables, staging buffers */
+
+typedef struct lanczos_desc {
+    int32_t in_w, in_h;         /* IN_WIDTH, IN_HEIGHT  (pixels, FULL frame)                     */
+    int32_t out_w, out_h;       /* OUT_WIDTH, OUT_HEIGHT (pixels, FULL frame) = in * N / D         */
+    int32_t channels;           /* NUM_CHANNELS: 1, 3 or 4, interleaved                            */
+    int32_t bytes_per_sample;   /* 1 (u8, the reference) or 2 (u16 generalisation, clamp 65535)    */
+    int32_t scale_n, scale_d;   /* SCALE_N / SCALE_D, must be > 1                                  */
+    int32_t a;                  /* LANCZOS_A: 2, 3 or 4                                            */
+    int32_t mode;               /* LANCZOS_MODE_*                                                  */
+    /* Row strip of the frame to produce (multi-GPU tile sharding).  out_rows == 0 means the whole
+     * frame.  With a strip, `in` points at input row lanczos_strip_input_rows().in_row0 and `out`
+     * at output row out_row0; both keep the full-frame row pitch. */
+    int32_t out_row0, out_rows;
+    int32_t reserved[3];
+} lanczos_desc;
+
+/* ---- descriptor helpers (host only, no GPU needed) ---- */
+/* Fill a descriptor for a whole frame; out dims = in * n / d (integer division, as OUT_WIDTH = IN_WIDTH*3). */
+int lanczos_desc_init(lanczos_desc* d, int in_w, int in_h, int channels, int bytes_per_sample,
+                      int scale_n, int scale_d, int a);
+int lanczos_validate(const lanczos_desc* d);
+/* K: output rows [0,K) depend on already-written output rows (in-place vertical pass). */
+int lanczos_inplace_rows(const lanczos_desc* d);
+/* Input rows [*in_row0, *in_row0 + *in_rows) needed to produce output rows [out_row0, out_row0+out_rows). */
+int lanczos_strip_input_rows(const lanczos_desc* d, int out_row0, int out_rows, int* in_row0, int* in_rows);
+size_t lanczos_in_frame_bytes(const lanczos_desc* d);   /* full frame */
+size_t lanczos_out_frame_bytes(const lanczos_desc* d);  /* full frame */
+
+/* ---- weights (host, double) ---- */
+double lanczos_kernel(double x, int a);                                                /* full_TB.h:51-53 */
+double lanczos_kernel_idx(int in_idx, int out_idx, int scale_n, int scale_d, int a);   /* kernel.h:6     */
+/* Tap table of one axis (0 = horizontal, 1 = vertical): for every output index o, first[o] =
+ * floor(x)-a+1 and weights[o*2a + k] = L(x - (first[o]+k)), zero where the tap is out of range. */
+int lanczos_taps_host(const lanczos_desc* d, int axis, int32_t* first, double* weights);
+
+/* ---- context ---- */
+int lanczos_create(lanczos_ctx** ctx, int device);
+int lanczos_destroy(lanczos_ctx* ctx);
+
+/* ---- the resample ---- */
+/* Host buffers (what stbi_load returned / what stbi_write_png takes), `frames` frames back to back.
+ * Synchronous: copies in, runs, copies out. */
+int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* in, void* out, int frames);
+/* Device buffers, asynchronous on `stream` (a hipStream_t; NULL = the context's own stream).
+ * Frame f starts at in + f*in_frame_stride / out + f*out_frame_stride (bytes; 0 = tightly packed). */
+int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in, void* d_out,
+                            int frames, size_t in_frame_stride, size_t out_frame_stride, void* stream);
+/* The reference's call shape: sizes as plain ints, RGB8 in/out, scale = out_w/in_w reduced. */
+int lanczos_u8(lanczos_ctx* ctx, const uint8_t* in, int in_w, int in_h, int channels,
+               uint8_t* out, int out_w, int out_h, int a);
+
+/* ---- measurement / introspection ---- */
+/* When enabled, every lanczos_resample_device call brackets its main kernel with HIP events on the
+ * launch stream. lanczos_timing_read synchronises, returns and resets the sums. */
+int lanczos_timing_enable(lanczos_ctx* ctx, int on);
+int lanczos_timing_read(lanczos_ctx* ctx, int* launches, double* main_kernel_ms, double* prefix_kernel_ms);
+int lanczos_last_kernel(const lanczos_ctx* ctx);
+int lanczos_last_hip_error(const lanczos_ctx* ctx);
+/* Force a kernel family for A/B tests: LANCZOS_KERNEL_NONE (auto), _GENERIC or _FAST. */
+int lanczos_force_kernel(lanczos_ctx* ctx, int family);
+const char* lanczos_strerror(int code);
+const char* lanczos_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANCZOS_HIP_H */

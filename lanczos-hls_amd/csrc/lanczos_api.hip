@@ -1,0 +1,464 @@
+// lanczos_api.hip -- the extern "C" boundary (include/lanczos_hip.h) over the HIP kernels.
+//
+// Replaces, for the resample path only: lanczos() (lanczos.cpp:86-98) with its strip scheduler
+// process_channel (lanczos.cpp:68-83), the Col/Row workers (worker.cpp:134-284), the weight ROM
+// (kernel.cpp:40-67) and the cyclic line buffer (cyclic_buffer.h).  Here: host-tabulated taps that stay
+// resident on the device, one fused H+V kernel launch per batch of frames, and a tiny second launch for
+// the in-place prefix rows.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/lanczos_hip.h"
+#include "lanczos_fast.hpp"
+#include "lanczos_generic.hpp"
+#include "lanczos_kernels_common.hpp"
+#include "lanczos_taps.hpp"
+
+namespace {
+
+struct PlanKey {
+    int in_w, in_h, out_w, out_h, channels, bps, sn, sd, a;
+    bool operator<(const PlanKey& o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
+};
+
+struct Plan {
+    lz::AxisTaps H, V;
+    lz::PrefixInfo prefix;
+    lz::TapTables dev{};       // device copies
+    void* dev_block = nullptr;  // one allocation behind `dev`
+    lz::FastConsts fast{};      // phase weights etc. for the specialised kernels
+    bool fast_ok = false;
+};
+
+}  // namespace
+
+struct lanczos_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::map<PlanKey, Plan*> plans;
+    std::mutex mu;
+    int last_kernel = LANCZOS_KERNEL_NONE;
+    int last_hip = 0;
+    int force = LANCZOS_KERNEL_NONE;
+    // staging for lanczos_resample_host
+    void* stage_in = nullptr;
+    void* stage_out = nullptr;
+    size_t stage_in_bytes = 0, stage_out_bytes = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // triples: main start, main stop / prefix stop
+    int ev_used = 0;
+    int launches = 0;
+    double main_ms = 0, prefix_ms = 0;
+};
+
+namespace {
+
+#define LZ_HIP(ctx, call)                                  \
+    do {                                                   \
+        hipError_t e_ = (call);                            \
+        if (e_ != hipSuccess) {                            \
+            (ctx)->last_hip = (int)e_;                     \
+            return LANCZOS_ERR_HIP;                        \
+        }                                                  \
+    } while (0)
+
+int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
+    PlanKey key;
+    memset(&key, 0, sizeof(key));
+    key = PlanKey{d->in_w, d->in_h, d->out_w, d->out_h, d->channels, d->bytes_per_sample,
+                  d->scale_n, d->scale_d, d->a};
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end()) {
+        *out = it->second;
+        return LANCZOS_OK;
+    }
+    Plan* p = new (std::nothrow) Plan();
+    if (!p) return LANCZOS_ERR_NOMEM;
+    lz::build_axis(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &p->H);
+    lz::build_axis(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &p->V);
+    p->prefix = lz::prefix_info(p->V);
+    const int taps = 2 * d->a;
+    // one device block: h_first | v_first | h_w | v_w  (8-byte aligned sections)
+    size_t off_hf = 0;
+    size_t off_vf = off_hf + (((size_t)d->out_w * 4 + 7) & ~(size_t)7);
+    size_t off_hw = off_vf + (((size_t)d->out_h * 4 + 7) & ~(size_t)7);
+    size_t off_vw = off_hw + (size_t)d->out_w * taps * 8;
+    size_t total = off_vw + (size_t)d->out_h * taps * 8;
+    std::vector<uint8_t> host(total, 0);
+    memcpy(host.data() + off_hf, p->H.first.data(), (size_t)d->out_w * 4);
+    memcpy(host.data() + off_vf, p->V.first.data(), (size_t)d->out_h * 4);
+    memcpy(host.data() + off_hw, p->H.w.data(), (size_t)d->out_w * taps * 8);
+    memcpy(host.data() + off_vw, p->V.w.data(), (size_t)d->out_h * taps * 8);
+    hipError_t e = hipMalloc(&p->dev_block, total);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        delete p;
+        return LANCZOS_ERR_HIP;
+    }
+    e = hipMemcpy(p->dev_block, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        (void)hipFree(p->dev_block);
+        delete p;
+        return LANCZOS_ERR_HIP;
+    }
+    uint8_t* b = (uint8_t*)p->dev_block;
+    p->dev.h_first = (const int32_t*)(b + off_hf);
+    p->dev.v_first = (const int32_t*)(b + off_vf);
+    p->dev.h_w = (const double*)(b + off_hw);
+    p->dev.v_w = (const double*)(b + off_vw);
+    p->fast_ok = lz::fast_prepare(*d, p->H, p->V, &p->fast);
+    ctx->plans[key] = p;
+    *out = p;
+    return LANCZOS_OK;
+}
+
+int whole_or_strip(const lanczos_desc* d, int* row0, int* rows) {
+    if (d->out_rows == 0) {
+        *row0 = 0;
+        *rows = d->out_h;
+    } else {
+        *row0 = d->out_row0;
+        *rows = d->out_rows;
+    }
+    return LANCZOS_OK;
+}
+
+void strip_input_rows(const lz::AxisTaps& V, int a, int in_h, int row0, int rows, const lz::PrefixInfo& pi,
+                      int* in_row0, int* in_rows) {
+    int lo = V.first[row0];
+    int hi = V.first[row0 + rows - 1] + 2 * a - 1;
+    if (row0 < pi.K && pi.M2 - 1 > hi) hi = pi.M2 - 1;  // the in-place prefix reads a little deeper
+    if (lo < 0) lo = 0;
+    if (hi > in_h - 1) hi = in_h - 1;
+    *in_row0 = lo;
+    *in_rows = hi - lo + 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lanczos_version(void) { return "lanczos-hls_amd 0.1 (gfx950)"; }
+
+const char* lanczos_strerror(int code) {
+    switch (code) {
+        case LANCZOS_OK: return "ok";
+        case LANCZOS_ERR_BAD_ARG: return "bad argument (null pointer, size, channels, a, or out != in*N/D)";
+        case LANCZOS_ERR_UNSUPPORTED: return "unsupported configuration (scale <= 1 or in-place prefix too deep)";
+        case LANCZOS_ERR_NO_DEVICE: return "no HIP device";
+        case LANCZOS_ERR_HIP: return "HIP runtime error";
+        case LANCZOS_ERR_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+int lanczos_desc_init(lanczos_desc* d, int in_w, int in_h, int channels, int bytes_per_sample, int scale_n,
+                      int scale_d, int a) {
+    if (!d) return LANCZOS_ERR_BAD_ARG;
+    memset(d, 0, sizeof(*d));
+    if (scale_n <= 0 || scale_d <= 0) return LANCZOS_ERR_BAD_ARG;
+    const int g = lz::gcd(scale_n, scale_d);  // lanczos.h:110: the reference reduces N/D by their gcd
+    d->in_w = in_w;
+    d->in_h = in_h;
+    d->scale_n = scale_n / g;
+    d->scale_d = scale_d / g;
+    d->out_w = (int)((long long)in_w * d->scale_n / d->scale_d);
+    d->out_h = (int)((long long)in_h * d->scale_n / d->scale_d);
+    d->channels = channels;
+    d->bytes_per_sample = bytes_per_sample;
+    d->a = a;
+    d->mode = LANCZOS_MODE_LSB1;
+    return lz::validate(d);
+}
+
+int lanczos_validate(const lanczos_desc* d) { return lz::validate(d); }
+
+int lanczos_inplace_rows(const lanczos_desc* d) {
+    if (lz::validate(d) != LANCZOS_OK) return -1;
+    lz::AxisTaps V;
+    lz::build_axis(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &V);
+    return lz::prefix_info(V).K;
+}
+
+int lanczos_strip_input_rows(const lanczos_desc* d, int out_row0, int out_rows, int* in_row0, int* in_rows) {
+    int rc = lz::validate(d);
+    if (rc != LANCZOS_OK) return rc;
+    if (!in_row0 || !in_rows || out_row0 < 0 || out_rows <= 0 || out_row0 + out_rows > d->out_h)
+        return LANCZOS_ERR_BAD_ARG;
+    lz::AxisTaps V;
+    lz::build_axis(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &V);
+    strip_input_rows(V, d->a, d->in_h, out_row0, out_rows, lz::prefix_info(V), in_row0, in_rows);
+    return LANCZOS_OK;
+}
+
+size_t lanczos_in_frame_bytes(const lanczos_desc* d) {
+    return d ? (size_t)d->in_w * d->in_h * d->channels * d->bytes_per_sample : 0;
+}
+size_t lanczos_out_frame_bytes(const lanczos_desc* d) {
+    return d ? (size_t)d->out_w * d->out_h * d->channels * d->bytes_per_sample : 0;
+}
+
+double lanczos_kernel(double x, int a) { return lz::kernel(x, a); }
+
+double lanczos_kernel_idx(int in_idx, int out_idx, int scale_n, int scale_d, int a) {
+    // the software model's argument for (output index, input index): x - i with x = out / SCALE
+    // (full_TB.h:57,60).  The HLS twin looks up |out*SCALE_D - in*SCALE_N| / SCALE_N (kernel.cpp:56-58),
+    // the same point up to the rounding of the division.
+    const double SCALE = (double)scale_n / scale_d;
+    const double x = (double)out_idx / SCALE;
+    return lz::kernel(x - in_idx, a);
+}
+
+int lanczos_taps_host(const lanczos_desc* d, int axis, int32_t* first, double* weights) {
+    int rc = lz::validate(d);
+    if (rc != LANCZOS_OK) return rc;
+    if (!first || !weights || (axis != 0 && axis != 1)) return LANCZOS_ERR_BAD_ARG;
+    lz::AxisTaps t;
+    if (axis == 0)
+        lz::build_axis(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &t);
+    else
+        lz::build_axis(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &t);
+    memcpy(first, t.first.data(), t.first.size() * sizeof(int32_t));
+    memcpy(weights, t.w.data(), t.w.size() * sizeof(double));
+    return LANCZOS_OK;
+}
+
+int lanczos_create(lanczos_ctx** out, int device) {
+    if (!out) return LANCZOS_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return LANCZOS_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return LANCZOS_ERR_NO_DEVICE;
+    lanczos_ctx* ctx = new (std::nothrow) lanczos_ctx();
+    if (!ctx) return LANCZOS_ERR_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return LANCZOS_ERR_HIP;
+    }
+    *out = ctx;
+    return LANCZOS_OK;
+}
+
+int lanczos_destroy(lanczos_ctx* ctx) {
+    if (!ctx) return LANCZOS_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->plans) {
+        if (kv.second->dev_block) (void)hipFree(kv.second->dev_block);
+        delete kv.second;
+    }
+    for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->stage_in) (void)hipFree(ctx->stage_in);
+    if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return LANCZOS_OK;
+}
+
+int lanczos_timing_enable(lanczos_ctx* ctx, int on) {
+    if (!ctx) return LANCZOS_ERR_BAD_ARG;
+    ctx->timing = on != 0;
+    return LANCZOS_OK;
+}
+
+static int timing_flush(lanczos_ctx* ctx) {
+    for (int i = 0; i + 2 < ctx->ev_used; i += 3) {
+        float a = 0, b = 0;
+        LZ_HIP(ctx, hipEventSynchronize(ctx->ev[i + 2]));
+        LZ_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[i], ctx->ev[i + 1]));
+        LZ_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[i + 1], ctx->ev[i + 2]));
+        ctx->main_ms += a;
+        ctx->prefix_ms += b;
+        ctx->launches++;
+    }
+    ctx->ev_used = 0;
+    return LANCZOS_OK;
+}
+
+int lanczos_timing_read(lanczos_ctx* ctx, int* launches, double* main_kernel_ms, double* prefix_kernel_ms) {
+    if (!ctx) return LANCZOS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    int rc = timing_flush(ctx);
+    if (rc != LANCZOS_OK) return rc;
+    if (launches) *launches = ctx->launches;
+    if (main_kernel_ms) *main_kernel_ms = ctx->main_ms;
+    if (prefix_kernel_ms) *prefix_kernel_ms = ctx->prefix_ms;
+    ctx->launches = 0;
+    ctx->main_ms = ctx->prefix_ms = 0;
+    return LANCZOS_OK;
+}
+
+int lanczos_last_kernel(const lanczos_ctx* ctx) { return ctx ? ctx->last_kernel : LANCZOS_KERNEL_NONE; }
+int lanczos_last_hip_error(const lanczos_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+int lanczos_force_kernel(lanczos_ctx* ctx, int family) {
+    if (!ctx || family < LANCZOS_KERNEL_NONE || family > LANCZOS_KERNEL_FAST) return LANCZOS_ERR_BAD_ARG;
+    ctx->force = family;
+    return LANCZOS_OK;
+}
+
+int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in, void* d_out, int frames,
+                            size_t in_frame_stride, size_t out_frame_stride, void* stream_v) {
+    if (!ctx || !d_in || !d_out || frames <= 0) return LANCZOS_ERR_BAD_ARG;
+    int rc = lz::validate(d);
+    if (rc != LANCZOS_OK) return rc;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    LZ_HIP(ctx, hipSetDevice(ctx->device));
+    Plan* p = nullptr;
+    rc = get_plan(ctx, d, &p);
+    if (rc != LANCZOS_OK) return rc;
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+
+    int row0, rows;
+    whole_or_strip(d, &row0, &rows);
+    int in_row0, in_rows;
+    strip_input_rows(p->V, d->a, d->in_h, row0, rows, p->prefix, &in_row0, &in_rows);
+    const bool has_prefix = row0 < p->prefix.K;
+    if (has_prefix) {
+        // the prefix recurrence needs rows [0,M) of the output and [0,M2) of the H pass in one place
+        if (row0 != 0) return LANCZOS_ERR_UNSUPPORTED;
+        if (p->prefix.M > lz::kMaxPrefixRows || p->prefix.M2 > lz::kMaxPrefixRows + lz::kMaxTaps)
+            return LANCZOS_ERR_UNSUPPORTED;
+    }
+
+    lz::FrameGeom g{};
+    g.in = (const uint8_t*)d_in;
+    g.out = (uint8_t*)d_out;
+    g.in_pitch = d->in_w * d->channels * d->bytes_per_sample;
+    g.out_pitch = d->out_w * d->channels * d->bytes_per_sample;
+    g.in_frame_stride = in_frame_stride ? in_frame_stride : (size_t)g.in_pitch * in_rows;
+    g.out_frame_stride = out_frame_stride ? out_frame_stride : (size_t)g.out_pitch * rows;
+    g.in_w = d->in_w;
+    g.in_h = d->in_h;
+    g.out_w = d->out_w;
+    g.out_h = d->out_h;
+    g.channels = d->channels;
+    g.a = d->a;
+    g.in_row0 = in_row0;
+    g.out_row0 = row0;
+    g.out_rows = rows;
+    g.skip_rows = has_prefix ? p->prefix.K : 0;
+    g.frames = frames;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    if (ctx->timing) {
+        if (ctx->ev_used + 3 > 3 * 4096) {
+            rc = timing_flush(ctx);
+            if (rc != LANCZOS_OK) return rc;
+        }
+        while ((int)ctx->ev.size() < ctx->ev_used + 3) {
+            hipEvent_t e;
+            LZ_HIP(ctx, hipEventCreate(&e));
+            ctx->ev.push_back(e);
+        }
+        ev0 = ctx->ev[ctx->ev_used];
+        ev1 = ctx->ev[ctx->ev_used + 1];
+        ev2 = ctx->ev[ctx->ev_used + 2];
+        ctx->ev_used += 3;
+        LZ_HIP(ctx, hipEventRecord(ev0, stream));
+    }
+
+    bool use_fast = p->fast_ok && ctx->force != LANCZOS_KERNEL_GENERIC &&
+                    lz::fast_supports(*d, g);
+    if (ctx->force == LANCZOS_KERNEL_FAST && !use_fast) return LANCZOS_ERR_UNSUPPORTED;
+    if (use_fast) {
+        hipError_t e = lz::fast_launch(*d, g, p->dev, p->fast, stream);
+        if (e != hipSuccess) {
+            ctx->last_hip = (int)e;
+            return LANCZOS_ERR_HIP;
+        }
+        ctx->last_kernel = LANCZOS_KERNEL_FAST;
+    } else {
+        const int samples_w = d->out_w * d->channels;
+        const int tiles_x = (samples_w + lz::kGenTileW - 1) / lz::kGenTileW;
+        const int tiles_y = (rows + lz::kGenTileH - 1) / lz::kGenTileH;
+        dim3 grid(tiles_x * tiles_y, frames);
+        if (d->bytes_per_sample == 1)
+            hipLaunchKernelGGL(lz::k_generic<uint8_t>, grid, dim3(lz::kGenTileW), 0, stream, g, p->dev);
+        else
+            hipLaunchKernelGGL(lz::k_generic<uint16_t>, grid, dim3(lz::kGenTileW), 0, stream, g, p->dev);
+        LZ_HIP(ctx, hipGetLastError());
+        ctx->last_kernel = LANCZOS_KERNEL_GENERIC;
+    }
+    if (ev1) LZ_HIP(ctx, hipEventRecord(ev1, stream));
+
+    if (has_prefix) {
+        const int samples_w = d->out_w * d->channels;
+        dim3 grid((samples_w + 255) / 256, frames);
+        if (d->bytes_per_sample == 1)
+            hipLaunchKernelGGL(lz::k_prefix<uint8_t>, grid, dim3(256), 0, stream, g, p->dev, p->prefix.K,
+                               p->prefix.M, p->prefix.M2);
+        else
+            hipLaunchKernelGGL(lz::k_prefix<uint16_t>, grid, dim3(256), 0, stream, g, p->dev, p->prefix.K,
+                               p->prefix.M, p->prefix.M2);
+        LZ_HIP(ctx, hipGetLastError());
+    }
+    if (ev2) LZ_HIP(ctx, hipEventRecord(ev2, stream));
+    return LANCZOS_OK;
+}
+
+int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* in, void* out, int frames) {
+    if (!ctx || !in || !out || frames <= 0) return LANCZOS_ERR_BAD_ARG;
+    int rc = lz::validate(d);
+    if (rc != LANCZOS_OK) return rc;
+    size_t in_bytes, out_bytes;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        LZ_HIP(ctx, hipSetDevice(ctx->device));
+        Plan* p = nullptr;
+        rc = get_plan(ctx, d, &p);
+        if (rc != LANCZOS_OK) return rc;
+        int row0, rows, in_row0, in_rows;
+        whole_or_strip(d, &row0, &rows);
+        strip_input_rows(p->V, d->a, d->in_h, row0, rows, p->prefix, &in_row0, &in_rows);
+        in_bytes = (size_t)d->in_w * d->channels * d->bytes_per_sample * in_rows * frames;
+        out_bytes = (size_t)d->out_w * d->channels * d->bytes_per_sample * rows * frames;
+        if (ctx->stage_in_bytes < in_bytes) {
+            if (ctx->stage_in) (void)hipFree(ctx->stage_in);
+            ctx->stage_in = nullptr;
+            ctx->stage_in_bytes = 0;
+            LZ_HIP(ctx, hipMalloc(&ctx->stage_in, in_bytes));
+            ctx->stage_in_bytes = in_bytes;
+        }
+        if (ctx->stage_out_bytes < out_bytes) {
+            if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+            ctx->stage_out = nullptr;
+            ctx->stage_out_bytes = 0;
+            LZ_HIP(ctx, hipMalloc(&ctx->stage_out, out_bytes));
+            ctx->stage_out_bytes = out_bytes;
+        }
+        LZ_HIP(ctx, hipMemcpyAsync(ctx->stage_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = lanczos_resample_device(ctx, d, ctx->stage_in, ctx->stage_out, frames, 0, 0, ctx->stream);
+    if (rc != LANCZOS_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        LZ_HIP(ctx, hipMemcpyAsync(out, ctx->stage_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        LZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return LANCZOS_OK;
+}
+
+int lanczos_u8(lanczos_ctx* ctx, const uint8_t* in, int in_w, int in_h, int channels, uint8_t* out, int out_w,
+               int out_h, int a) {
+    if (in_w <= 0 || in_h <= 0 || out_w <= 0 || out_h <= 0) return LANCZOS_ERR_BAD_ARG;
+    lanczos_desc d;
+    // SCALE_N/SCALE_D = OUT_WIDTH/IN_WIDTH reduced (lanczos.h:110-114)
+    int rc = lanczos_desc_init(&d, in_w, in_h, channels, 1, out_w, in_w, a);
+    if (rc != LANCZOS_OK) return rc;
+    if (d.out_w != out_w || d.out_h != out_h) return LANCZOS_ERR_BAD_ARG;  // full_TB.h:115-118
+    return lanczos_resample_host(ctx, &d, in, out, 1);
+}
+
+}  // extern "C"

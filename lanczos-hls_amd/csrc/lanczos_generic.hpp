@@ -1,0 +1,150 @@
+// lanczos_generic.hpp -- table-driven kernels for ANY rational scale > 1, channel count and a.
+//
+//   k_generic  : one workgroup = 256 sample columns x 32 output rows.  The horizontal pass of the
+//                input rows that tile needs goes to LDS as truncated integers (the reference's
+//                between-pass store, full_TB.h:63), the vertical pass reads it back.  All sums are
+//                f64 with a separate multiply and add per tap in ascending tap order, so every
+//                sample is bit-identical to lanczos_expected() (full_TB.h:79-96).
+//   k_prefix   : the first K output rows.  The reference's vertical pass runs in place from the
+//                bottom row up (full_TB.h:67-77): for xx < K some taps i > xx read rows that already
+//                hold OUTPUT values.  That is a short sequential recurrence per column; one thread
+//                walks it for one sample column, entirely in f64.
+//
+// These are the always-exact fallback; the specialised kernels of lanczos_fast.hpp serve the
+// integer-scale configurations the benchmark is quoted on.
+#pragma once
+#include "lanczos_kernels_common.hpp"
+#include "lanczos_taps.hpp"
+
+namespace lz {
+
+constexpr int kGenTileW = 256;   // sample columns per workgroup (= threads)
+constexpr int kGenTileH = 32;    // output rows per workgroup
+constexpr int kGenMaxHRows = kGenTileH + 2 * kMaxA;  // S > 1: rows spanned <= TH/S + 2a
+
+template <typename T>
+__global__ __launch_bounds__(kGenTileW) void k_generic(FrameGeom g, TapTables t) {
+    __shared__ T hbuf[kGenMaxHRows][kGenTileW];
+
+    const int taps = 2 * g.a;
+    const int C = g.channels;
+    const int samples_w = g.out_w * C;
+    const int tiles_x = (samples_w + kGenTileW - 1) / kGenTileW;
+    const int tx = blockIdx.x % tiles_x;
+    const int ty = blockIdx.x / tiles_x;
+    const int frame = blockIdx.y;
+
+    const int y_begin = g.out_row0 + ty * kGenTileH;
+    int y_end = y_begin + kGenTileH;
+    if (y_end > g.out_row0 + g.out_rows) y_end = g.out_row0 + g.out_rows;
+    if (y_end <= g.skip_rows) return;  // the whole tile belongs to the prefix kernel (uniform)
+
+    // input rows this tile reads (clamped to the image; out-of-range taps carry weight 0)
+    int r_lo = t.v_first[y_begin];
+    int r_hi = t.v_first[y_end - 1] + taps - 1;
+    if (r_lo < 0) r_lo = 0;
+    if (r_hi > g.in_h - 1) r_hi = g.in_h - 1;
+
+    const int j = tx * kGenTileW + threadIdx.x;  // sample column
+    const bool active = j < samples_w;
+    const uint8_t* in_f = g.in + (size_t)frame * g.in_frame_stride;
+    uint8_t* out_f = g.out + (size_t)frame * g.out_frame_stride;
+
+    // ---- horizontal pass (full_TB.h:55-65) for rows r_lo..r_hi of this column ----
+    if (active) {
+        const int xx = j / C, c = j - xx * C;
+        const int first = t.h_first[xx];
+        double w[kMaxTaps];
+        int idx[kMaxTaps];
+#pragma unroll
+        for (int k = 0; k < kMaxTaps; k++) {
+            if (k < taps) {
+                w[k] = t.h_w[(size_t)xx * taps + k];
+                int i = first + k;
+                i = i < 0 ? 0 : (i > g.in_w - 1 ? g.in_w - 1 : i);  // weight is 0 there
+                idx[k] = i * C + c;
+            } else {
+                w[k] = 0.0;
+                idx[k] = 0;
+            }
+        }
+        for (int r = r_lo; r <= r_hi; r++) {
+            const T* row = (const T*)(in_f + (size_t)(r - g.in_row0) * g.in_pitch);
+            double sum = 0;
+#pragma unroll
+            for (int k = 0; k < kMaxTaps; k++)
+                if (k < taps) sum += (double)row[idx[k]] * w[k];
+            hbuf[r - r_lo][threadIdx.x] = store_convert<T>(sum);
+        }
+    }
+    __syncthreads();
+
+    // ---- vertical pass (full_TB.h:67-77, rows >= K: every tap reads an H-pass row) ----
+    if (active) {
+        for (int y = y_begin; y < y_end; y++) {
+            if (y < g.skip_rows) continue;
+            const int first = t.v_first[y];
+            const double* wv = t.v_w + (size_t)y * taps;
+            double sum = 0;
+            for (int k = 0; k < taps; k++) {
+                int i = first + k;
+                i = i < r_lo ? r_lo : (i > r_hi ? r_hi : i);  // weight is 0 outside the image
+                sum += (double)hbuf[i - r_lo][threadIdx.x] * wv[k];
+            }
+            T* orow = (T*)(out_f + (size_t)(y - g.out_row0) * g.out_pitch);
+            orow[j] = store_convert<T>(sum);
+        }
+    }
+}
+
+// One thread per (frame, sample column): output rows [0, K) of the in-place vertical pass.
+// pi.M / pi.M2 <= kMaxPrefixRows + kMaxTaps are checked on the host.
+template <typename T>
+__global__ __launch_bounds__(256) void k_prefix(FrameGeom g, TapTables t, int K, int M, int M2) {
+    const int C = g.channels;
+    const int taps = 2 * g.a;
+    const int samples_w = g.out_w * C;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int frame = blockIdx.y;
+    if (j >= samples_w) return;
+    const uint8_t* in_f = g.in + (size_t)frame * g.in_frame_stride;
+    uint8_t* out_f = g.out + (size_t)frame * g.out_frame_stride;
+
+    T h[kMaxPrefixRows + kMaxTaps];  // H-pass rows 0..M2-1 of this column
+    T o[kMaxPrefixRows + kMaxTaps];  // output rows 0..M-1 of this column
+
+    {   // horizontal pass of the rows the prefix reads (full_TB.h:55-65)
+        const int xx = j / C, c = j - xx * C;
+        const int first = t.h_first[xx];
+        for (int r = 0; r < M2; r++) {
+            const T* row = (const T*)(in_f + (size_t)(r - g.in_row0) * g.in_pitch);
+            double sum = 0;
+            for (int k = 0; k < taps; k++) {
+                int i = first + k;
+                i = i < 0 ? 0 : (i > g.in_w - 1 ? g.in_w - 1 : i);
+                sum += (double)row[i * C + c] * t.h_w[(size_t)xx * taps + k];
+            }
+            h[r] = store_convert<T>(sum);
+        }
+    }
+    // full_TB.h:69-76, xx descending: a tap at row i > xx sees the value already written there
+    for (int xx = M - 1; xx >= 0; xx--) {
+        const int first = t.v_first[xx];
+        const double* wv = t.v_w + (size_t)xx * taps;
+        double sum = 0;
+        for (int k = 0; k < taps; k++) {
+            int i = first + k;
+            i = i < 0 ? 0 : (i > g.in_h - 1 ? g.in_h - 1 : i);  // weight 0 outside
+            const T v = i > xx ? o[i] : h[i];
+            sum += (double)v * wv[k];
+        }
+        o[xx] = store_convert<T>(sum);
+    }
+    for (int xx = 0; xx < K; xx++) {
+        if (xx < g.out_row0 || xx >= g.out_row0 + g.out_rows) continue;
+        T* orow = (T*)(out_f + (size_t)(xx - g.out_row0) * g.out_pitch);
+        orow[j] = o[xx];
+    }
+}
+
+}  // namespace lz

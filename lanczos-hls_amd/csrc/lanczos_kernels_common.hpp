@@ -1,0 +1,42 @@
+// lanczos_kernels_common.hpp -- parameter blocks and device helpers shared by the HIP kernels.
+// The translation unit is compiled with -ffp-contract=off: a*b+c written with operators is TWO
+// roundings everywhere (what the reference's x86-64 build does, full_TB.h:60,73); fused multiply-adds
+// appear only where they are spelled __builtin_fmaf / __builtin_fma.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace lz {
+
+struct FrameGeom {
+    // all pitches/strides in BYTES; dims in pixels; sample = one channel of one pixel
+    const uint8_t* in;   // first input row held by the caller (= full-frame row in_row0)
+    uint8_t* out;        // first output row to write (= full-frame row out_row0)
+    unsigned long long in_frame_stride, out_frame_stride;
+    int in_pitch, out_pitch;
+    int in_w, in_h, out_w, out_h;  // full frame
+    int channels, a;
+    int in_row0;          // full-frame index of the first row behind `in`
+    int out_row0, out_rows;  // strip to produce
+    int skip_rows;        // output rows < skip_rows are left to the in-place prefix kernel
+    int frames;
+};
+
+struct TapTables {
+    const int32_t* h_first;  // [out_w]
+    const double* h_w;       // [out_w][2a]
+    const int32_t* v_first;  // [out_h]
+    const double* v_w;       // [out_h][2a]
+};
+
+// full_TB.h:29-37: x > max -> max; x < 0 -> 0; else truncate
+template <typename T>
+__device__ __forceinline__ T store_convert(double x) {
+    constexpr double kMax = sizeof(T) == 1 ? 255.0 : 65535.0;
+    if (x > kMax) return (T)kMax;
+    if (x < 0) return (T)0;
+    return (T)(unsigned)x;
+}
+
+}  // namespace lz

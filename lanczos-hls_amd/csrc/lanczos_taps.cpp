@@ -1,0 +1,113 @@
+// lanczos_taps.cpp -- host-side tap tables and descriptor arithmetic.  See lanczos_taps.hpp.
+// Compiled with -ffp-contract=off: the doubles computed here must be the ones the reference's
+// software model computes (full_TB.h:51-53), they feed the exact device paths.
+#include "lanczos_taps.hpp"
+
+#include <cmath>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace lz {
+
+// full_TB.h:39-44
+double sinc(double x) {
+    if (x == 0) return 1;
+    return std::sin(x) / x;
+}
+
+// full_TB.h:51-53: sinc(M_PI * x) * sinc(M_PI * x / LANCZOS_A), evaluated left to right
+double kernel(double x, int a) { return sinc(M_PI * x) * sinc(M_PI * x / a); }
+
+int gcd(int a, int b) { return b != 0 ? gcd(b, a % b) : a; }
+
+void build_axis(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* t) {
+    t->in_n = in_n;
+    t->out_n = out_n;
+    t->a = a;
+    t->first.assign(out_n, 0);
+    t->w.assign((size_t)out_n * 2 * a, 0.0);
+    const double SCALE = (double)scale_n / scale_d;  // lanczos.h:112
+    for (int o = 0; o < out_n; o++) {
+        const double x = (double)o / SCALE;           // full_TB.h:57 / :70
+        const int first = (int)(std::floor(x) - a + 1);
+        t->first[o] = first;
+        for (int k = 0; k < 2 * a; k++) {
+            const int i = first + k;
+            // taps outside [0, in_n-1] are dropped by the loop bounds of full_TB.h:59/:72;
+            // a zero weight contributes an exact +-0 to the sum, which is the same thing
+            t->w[(size_t)o * 2 * a + k] = (i >= 0 && i <= in_n - 1) ? kernel(x - i, a) : 0.0;
+        }
+    }
+}
+
+PrefixInfo prefix_info(const AxisTaps& v) {
+    PrefixInfo p;
+    const int taps = 2 * v.a;
+    auto last_tap = [&](int o) {
+        int last = v.first[o] + taps - 1;
+        return last > v.in_n - 1 ? v.in_n - 1 : last;
+    };
+    for (int o = 0; o < v.out_n; o++)
+        if (last_tap(o) > o) p.K = o + 1;
+    p.M = p.K;
+    for (int o = 0; o < p.K; o++)
+        if (last_tap(o) + 1 > p.M) p.M = last_tap(o) + 1;
+    p.M2 = 0;
+    for (int o = 0; o < p.M && o < v.out_n; o++)
+        if (last_tap(o) + 1 > p.M2) p.M2 = last_tap(o) + 1;
+    return p;
+}
+
+int validate(const lanczos_desc* d) {
+    if (!d) return LANCZOS_ERR_BAD_ARG;
+    if (d->in_w <= 0 || d->in_h <= 0 || d->out_w <= 0 || d->out_h <= 0) return LANCZOS_ERR_BAD_ARG;
+    if (d->channels != 1 && d->channels != 3 && d->channels != 4) return LANCZOS_ERR_BAD_ARG;
+    if (d->bytes_per_sample != 1 && d->bytes_per_sample != 2) return LANCZOS_ERR_BAD_ARG;
+    if (d->a < 2 || d->a > kMaxA) return LANCZOS_ERR_BAD_ARG;
+    if (d->scale_n <= 0 || d->scale_d <= 0) return LANCZOS_ERR_BAD_ARG;
+    if (d->mode != LANCZOS_MODE_LSB1 && d->mode != LANCZOS_MODE_EXACT) return LANCZOS_ERR_BAD_ARG;
+    // the harness rejects images whose size is not the compiled-in one (full_TB.h:115-118);
+    // here: the output must be the input scaled by N/D (integer division, as OUT_WIDTH = IN_WIDTH*3)
+    if ((long long)d->in_w * d->scale_n / d->scale_d != d->out_w) return LANCZOS_ERR_BAD_ARG;
+    if ((long long)d->in_h * d->scale_n / d->scale_d != d->out_h) return LANCZOS_ERR_BAD_ARG;
+    if (d->out_w > (1 << 20) || d->out_h > (1 << 20)) return LANCZOS_ERR_BAD_ARG;
+    if (d->out_row0 < 0 || d->out_rows < 0) return LANCZOS_ERR_BAD_ARG;
+    if (d->out_rows == 0 && d->out_row0 != 0) return LANCZOS_ERR_BAD_ARG;
+    if (d->out_row0 + d->out_rows > d->out_h) return LANCZOS_ERR_BAD_ARG;
+    // S <= 1: the in-place vertical pass of full_TB.h:67-77 would read written rows everywhere
+    if (d->scale_n <= d->scale_d) return LANCZOS_ERR_UNSUPPORTED;
+    return LANCZOS_OK;
+}
+
+double f32_chain_error_bound(const double* w, int ntaps, double maxv) {
+    double sabs = 0;
+    for (int k = 0; k < ntaps; k++) sabs += std::fabs(w[k]);
+    const double bmax = maxv * sabs + 1.0;  // any partial sum, bias included
+    const double u = std::ldexp(1.0, -24);  // f32 unit roundoff
+    // weight rounding (sabs*maxv*u) + one rounding per fmaf (ntaps * bmax * u), 5 % slack
+    return 1.05 * (ntaps + 1) * bmax * u;
+}
+
+int integer_phase_flip_limit(const double* wi, int a, int maxv) {
+    // Lower-bound chain (rounding is monotone): drop the positive tiny terms.  The negative terms in
+    // front of the centre accumulate to -nb; each negative term behind it is applied on its own.  If
+    // every one of these is smaller than half the spacing below v0 the sum never leaves v0.
+    double nb = 0, na = 0;
+    for (int k = 0; k < a - 1; k++)
+        if (wi[k] < 0) nb += -wi[k] * maxv;
+    for (int k = a; k < 2 * a; k++)
+        if (wi[k] < 0 && -wi[k] * maxv > na) na = -wi[k] * maxv;
+    const double need = (nb > na ? nb : na) * (1.0 + 1e-9);
+    int limit = 0;
+    for (int v0 = 1; v0 <= maxv; v0++) {
+        int e = std::ilogb((double)v0);
+        const bool pow2 = (v0 & (v0 - 1)) == 0;
+        const double half_below = std::ldexp(1.0, pow2 ? e - 54 : e - 53);
+        if (!(need < half_below)) limit = v0;
+    }
+    return limit;
+}
+
+}  // namespace lz

@@ -1,0 +1,51 @@
+// lanczos_taps.hpp -- host-side tap tables and descriptor arithmetic (no HIP, no GPU needed).
+//
+// The reference evaluates its weights per tap with two libm sin() calls inside the hot loop
+// (full_TB.h:51-53,60,73) or, in the HLS path, from a ROM of a*SCALE_N+1 entries indexed by
+// |out*SCALE_D - in*SCALE_N| (kernel.cpp:40-59).  Here the weights of one axis are tabulated once
+// per (size, scale, a) on the host -- with exactly the double expressions of the software model, so
+// the exact (f64) device paths reproduce its sums bit for bit -- and stay resident on the device.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/lanczos_hip.h"
+
+namespace lz {
+
+constexpr int kMaxA = 4;
+constexpr int kMaxTaps = 2 * kMaxA;
+constexpr int kMaxPrefixRows = 64;  // deepest in-place prefix (rows that read written rows) we run
+
+// full_TB.h:39-44 and :51-53
+double sinc(double x);
+double kernel(double x, int a);
+
+struct AxisTaps {
+    int in_n = 0, out_n = 0, a = 0;
+    std::vector<int32_t> first;  // [out_n]      floor(x) - a + 1 (may be negative)
+    std::vector<double> w;       // [out_n][2a]  L(x - (first+k)); 0 where first+k is outside [0,in_n-1]
+};
+
+// x = (double)o / ((double)n/d)  (full_TB.h:57,70 with SCALE of lanczos.h:112)
+void build_axis(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* t);
+
+struct PrefixInfo {
+    int K = 0;   // output rows [0,K) read rows i > xx, i.e. already-written OUTPUT rows (full_TB.h:67-77)
+    int M = 0;   // those reads reach output rows < M  (M >= K)
+    int M2 = 0;  // rows [K,M) are ordinary rows; they read H-pass rows < M2
+};
+PrefixInfo prefix_info(const AxisTaps& v);
+
+int validate(const lanczos_desc* d);
+int gcd(int a, int b);  // stb.cpp:9-12 (the reference reduces SCALE_N/SCALE_D with it, lanczos.h:110)
+
+// f32 error bound of an n-tap fmaf chain against the exact sum, for samples <= maxv and the given
+// weights: used as the half-width of the "too close to an integer to trust f32" window.
+double f32_chain_error_bound(const double* w, int ntaps, double maxv);
+
+// Largest centre sample v0 for which the integer-phase double chain can still end below v0
+// (SURVEY.md Q4); every v0 above it provably comes out unchanged.  wi[k] = L(a-1-k), k = 0..2a-1.
+int integer_phase_flip_limit(const double* wi, int a, int maxv);
+
+}  // namespace lz

@@ -1,0 +1,12 @@
+"""Import shim: the package directory is named `lanczos-hls_amd/` (not a valid Python identifier), so
+`import lanczos_hls_amd` loads lanczos-hls_amd/__init__.py under this module name."""
+import importlib.util
+import os
+import sys
+
+_pkg_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lanczos-hls_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_pkg_dir, "__init__.py"), submodule_search_locations=[_pkg_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

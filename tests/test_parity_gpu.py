@@ -1,0 +1,209 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU checker.
+
+  * golden fixtures (reference outputs) and known-answer digests: bit-exact in EXACT mode
+  * oracle on seeded synthetic frames (noise / dark / gradient / blocks): EXACT mode bit-exact;
+    default LSB1 mode within +-1 LSB per sample (the tolerance BASELINE.json's north_star states)
+  * edge cases the reference's loop bounds imply: tiny images (every tap range clipped), a = 2/3/4,
+    1/3/4 channels, non-integer scales, the in-place prefix rows, strips, batches, u16
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lanczos_hls_amd as L
+import oracle_lib as O
+import patterns as P
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def _parse(key):
+    dims, out, sc, a, c = key.split("_")
+    iw, ih = (int(v) for v in dims.split("x"))
+    ow, oh = (int(v) for v in out.split("x"))
+    sn, sd = (int(v) for v in sc.split("-"))
+    return iw, ih, ow, oh, sn, sd, int(a[1:]), int(c[1:])
+
+
+def _oracle(img, sn, sd, a, threads=8):
+    h, w, c = img.shape
+    cfg = O.cfg(w, h, w * sn // sd, h * sn // sd, c, a, sn, sd)
+    if img.dtype == np.uint16:
+        return O.expected_hwc_u16(cfg, img, threads)
+    return O.expected_hwc_u8(cfg, img, threads)
+
+
+def _cmp(got, want, mode, what):
+    assert got.shape == want.shape and got.dtype == want.dtype, what
+    diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    if mode == L.MODE_EXACT:
+        assert diff.max() == 0, f"{what}: {np.count_nonzero(diff)} samples differ, max {diff.max()}"
+    else:
+        assert diff.max() <= 1, f"{what}: max |diff| {diff.max()} > 1 LSB"
+    return int(np.count_nonzero(diff))
+
+
+@pytest.mark.parametrize("family", [L.KERNEL_GENERIC, L.KERNEL_NONE])
+@pytest.mark.parametrize("mode", [L.MODE_EXACT, L.MODE_LSB1])
+def test_golden_fixtures(ctx, family, mode):
+    """Reference outputs committed under tests/golden (made by the reference's own compiled lines)."""
+    z = np.load(os.path.join(GOLD, "golden_small.npz"))
+    keys = sorted({k.rsplit(":", 1)[0] for k in z.files})
+    ctx.force_kernel(family)
+    try:
+        for k in keys:
+            shape, pname = k.split(":")
+            iw, ih, ow, oh, sn, sd, a, c = _parse(shape)
+            img = np.ascontiguousarray(z[k + ":in"].transpose(1, 2, 0))      # planar -> stb layout
+            want = np.ascontiguousarray(z[k + ":out"].transpose(1, 2, 0))
+            got = ctx.resample(img, sn, sd, a, mode)
+            _cmp(got, want, mode, k)
+    finally:
+        ctx.force_kernel(L.KERNEL_NONE)
+
+
+def test_known_answer_digests_full_size(ctx):
+    """BASELINE configs 2 and 3 at full size: FNV-1a-64 of the planar output equals the reference's
+    digest -- no CPU work needed on the box."""
+    with open(os.path.join(GOLD, "kat_digests.json")) as f:
+        kat = json.load(f)
+    for shape in ("1920x1080_3840x2160_2-1_a3_c3", "1280x720_3840x2160_3-1_a3_c3",
+                  "256x256_512x512_2-1_a2_c3", "480x270_960x540_2-1_a4_c4", "300x200_400x266_4-3_a3_c3"):
+        iw, ih, ow, oh, sn, sd, a, c = _parse(shape)
+        planar = O.lcg_u8(c * ih * iw, 12345).reshape(c, ih, iw)
+        got = ctx.resample(np.ascontiguousarray(planar.transpose(1, 2, 0)), sn, sd, a, L.MODE_EXACT)
+        assert got.shape == (oh, ow, c)
+        dig = O.fnv1a64(np.ascontiguousarray(got.transpose(2, 0, 1)))
+        assert f"{dig:016x}" == kat["survey_8c"][shape], shape
+
+
+SHAPES = [
+    # (in_w, in_h, channels, sn, sd, a)
+    (200, 120, 3, 2, 1, 3), (160, 90, 3, 3, 1, 3), (128, 96, 3, 2, 1, 2), (96, 64, 4, 2, 1, 4),
+    (150, 100, 3, 4, 3, 3), (120, 80, 1, 2, 1, 3), (90, 60, 4, 3, 1, 2), (100, 75, 3, 3, 2, 3),
+    (64, 33, 1, 5, 2, 4), (515, 131, 3, 2, 1, 3), (333, 77, 3, 3, 1, 3),
+]
+
+
+@pytest.mark.parametrize("mode", [L.MODE_EXACT, L.MODE_LSB1])
+@pytest.mark.parametrize("pattern", ["noise", "dark", "gradient", "blocks"])
+def test_oracle_parity_medium(ctx, pattern, mode):
+    for (w, h, c, sn, sd, a) in SHAPES:
+        img = P.ALL_U8[pattern](h, w, c)
+        want = _oracle(img, sn, sd, a)
+        got = ctx.resample(img, sn, sd, a, mode)
+        _cmp(got, want, mode, f"{pattern} {w}x{h}x{c} {sn}/{sd} a={a}")
+
+
+def test_tiny_images_all_taps_clipped(ctx):
+    """Images narrower/shorter than the 2a tap window: every loop bound of full_TB.h:59,72 clips."""
+    rng = np.random.default_rng(11)
+    for (w, h, c, sn, sd, a) in [(1, 1, 3, 2, 1, 3), (2, 3, 1, 2, 1, 4), (3, 2, 4, 3, 1, 3), (5, 4, 3, 2, 1, 2),
+                                 (4, 7, 3, 3, 2, 3), (7, 1, 3, 2, 1, 3), (1, 9, 4, 4, 1, 2)]:
+        img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        want = _oracle(img, sn, sd, a, threads=1)
+        for mode in (L.MODE_EXACT, L.MODE_LSB1):
+            got = ctx.resample(img, sn, sd, a, mode)
+            _cmp(got, want, mode, f"tiny {w}x{h}x{c} {sn}/{sd} a={a}")
+
+
+def test_extreme_values_saturate_like_the_reference(ctx):
+    """All-255 overshoots (phase-1/2 weight sum 1.019 at a=2, no renormalisation) -> clamp at 255;
+    checkerboards drive sums negative -> clamp at 0 (full_TB.h:29-37)."""
+    for a in (2, 3, 4):
+        full = np.full((40, 56, 3), 255, np.uint8)
+        chk = ((np.add.outer(np.arange(40), np.arange(56)) % 2) * 255).astype(np.uint8)[..., None].repeat(3, 2)
+        for img in (full, chk, np.zeros((40, 56, 3), np.uint8)):
+            want = _oracle(img, 2, 1, a)
+            got = ctx.resample(img, 2, 1, a, L.MODE_EXACT)
+            _cmp(got, want, L.MODE_EXACT, f"extreme a={a}")
+
+
+def test_inplace_prefix_rows_follow_the_reference(ctx):
+    """Rows < K must equal the in-place result (full_TB.h:67-77), which differs from a clean V pass."""
+    img = P.noise(64, 80, 3, seed=5)
+    for (sn, sd, a) in [(2, 1, 3), (3, 1, 3), (2, 1, 4), (4, 3, 3), (2, 1, 2)]:
+        d = L.make_desc(80, 64, 3, sn, sd, a)
+        K = L.inplace_rows(d)
+        cfg = O.cfg(80, 64, d.out_w, d.out_h, 3, a, sn, sd)
+        inplace = O.expected_hwc_u8(cfg, img)
+        clean = O.outofplace_hwc_u8(cfg, img)
+        got = ctx.resample(img, sn, sd, a, L.MODE_EXACT)
+        assert np.array_equal(got, inplace)
+        assert not np.array_equal(got[:K], clean[:K])
+
+
+def test_batch_of_frames(ctx):
+    frames = np.stack([P.noise(72, 96, 3, seed=100 + i) for i in range(5)])
+    got = ctx.resample(frames, 2, 1, 3, L.MODE_EXACT)
+    for i in range(5):
+        assert np.array_equal(got[i], _oracle(frames[i], 2, 1, 3))
+
+
+def test_row_strips_reassemble_to_the_whole_frame(ctx):
+    """BASELINE config 5's sharding: output row strips with an input halo, no other exchange."""
+    for (w, h, c, sn, sd, a, dtype) in [(96, 128, 4, 2, 1, 4, np.uint16), (120, 96, 3, 3, 1, 3, np.uint8),
+                                        (90, 64, 3, 4, 3, 3, np.uint8)]:
+        img = P.noise(h, w, c, seed=21, dtype=dtype)
+        want = _oracle(img, sn, sd, a)
+        oh = h * sn // sd
+        parts = 4
+        bounds = [oh * i // parts for i in range(parts + 1)]
+        out = []
+        for i in range(parts):
+            d = L.make_desc(w, h, c, sn, sd, a, img.dtype.itemsize, L.MODE_EXACT,
+                            out_row0=bounds[i], out_rows=bounds[i + 1] - bounds[i])
+            r0, n = L.strip_input_rows(d, d.out_row0, d.out_rows)
+            out.append(ctx.resample_strip(img[r0:r0 + n], d))
+        assert np.array_equal(np.concatenate(out), want)
+
+
+def test_u16_matches_the_templated_checker(ctx):
+    """parity unpinned by the reference (no 16-bit path, full_TB.h:18,30): checked against the same
+    restatement templated on the sample type (clamp 65535, truncation)."""
+    for (w, h, c, sn, sd, a) in [(96, 64, 4, 2, 1, 4), (80, 50, 3, 2, 1, 3), (64, 48, 1, 3, 1, 2)]:
+        img = P.noise(h, w, c, seed=9, dtype=np.uint16)
+        want = _oracle(img, sn, sd, a)
+        got = ctx.resample(img, sn, sd, a, L.MODE_EXACT)
+        _cmp(got, want, L.MODE_EXACT, f"u16 {w}x{h}x{c}")
+        got = ctx.resample(img, sn, sd, a, L.MODE_LSB1)
+        _cmp(got, want, L.MODE_LSB1, f"u16 {w}x{h}x{c}")
+
+
+def test_reference_call_shape_and_errors(ctx):
+    img = P.gradient_noise(48, 64, 3)
+    got = ctx.u8(img, 128, 96, 3)
+    _cmp(got, _oracle(img, 2, 1, 3), L.MODE_LSB1, "lanczos_u8")
+    with pytest.raises(L.LanczosError) as e:
+        ctx.u8(img, 130, 96, 3)          # wrong output size: full_TB.h:115-118
+    assert e.value.code == L.ERR_BAD_ARG
+    with pytest.raises(L.LanczosError) as e:
+        ctx.u8(img, 64, 48, 3)           # scale 1: unsupported
+    assert e.value.code == L.ERR_UNSUPPORTED
+    with pytest.raises(L.LanczosError):
+        ctx.resample(np.zeros((4, 4, 2), np.uint8), 2, 1, 3)   # 2 channels
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config 2 at full size without the CPU checker: determinism, frame independence inside a
+    batch, and constant frames map to the analytically known constant."""
+    f0 = P.noise(1080, 1920, 3, seed=1)
+    f1 = P.gradient_noise(1080, 1920, 3)
+    both = ctx.resample(np.stack([f0, f1]), 2, 1, 3)
+    assert np.array_equal(both[0], ctx.resample(f0, 2, 1, 3))
+    assert np.array_equal(both[1], ctx.resample(f1, 2, 1, 3))
+    flat = np.full((1080, 1920, 3), 100, np.uint8)
+    out = ctx.resample(flat, 2, 1, 3, L.MODE_EXACT)
+    small = _oracle(np.full((40, 40, 3), 100, np.uint8), 2, 1, 3)
+    assert np.array_equal(out[20:60, 20:60], small[20:60, 20:60])
+    assert np.array_equal(out[:40, :40], small[:40, :40])          # top-left corner incl. prefix rows
