@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- output Mpixels/s of the Lanczos resample hot path on N MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c1] [--pattern noise|gradient|blocks|dark]
+                    [--mode lsb1|exact] [--frames F] [--no-cpu-baseline] [--exchange]
+
+A "step" is ONE launch of the fused resample over a batch of F distinct synthetic frames that are already
+resident in HBM (F = 16 by default: 16 x 31.1 MB of compulsory traffic > the 256 MiB Infinity Cache, so
+steps that cycle through the same buffers still stream from HBM).  Frames shard across ranks with no
+data-path collective (weak scaling: F frames per GPU per step).  Rank 0 prints one JSON line.
+
+roofline.achieved = algorithmic bytes per launch (input + output bytes of the F frames)
+divided by the main kernel's average duration, measured with HIP events on the launch stream by the
+library (lanczos_timing_*).  cpu_baseline = the CPU restatement of the reference software path
+(oracle/, full_TB.h:29-96) timed on this host's cores on a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+CONFIGS = {
+    # name: (in_w, in_h, channels, bytes/sample, scale_n, scale_d, a, description)
+    "c1": (256, 256, 3, 1, 2, 1, 2, "256x256->512x512 RGB8 2x Lanczos-2"),
+    "c2": (1920, 1080, 3, 1, 2, 1, 3, "1920x1080->3840x2160 RGB8 2x Lanczos-3"),
+    "c3": (1280, 720, 3, 1, 3, 1, 3, "1280x720->3840x2160 RGB8 3x Lanczos-3"),
+    "c5": (3840, 2160, 4, 2, 2, 1, 4, "3840x2160->7680x4320 RGBA16 2x Lanczos-4"),
+}
+
+
+def make_frames(torch, pattern, frames, h, w, c, bps, device, seed):
+    """Synthetic frames of SURVEY.md 8(d), generated on the device (torch RNG; not the checker's LCG)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    hi = 256 if bps == 1 else 65536
+    dt = torch.uint8 if bps == 1 else torch.int32
+    if pattern == "noise":
+        x = torch.randint(0, hi, (frames, h, w, c), generator=gen, device=device, dtype=dt)
+    elif pattern == "dark":
+        x = torch.randint(0, hi * 72 // 256, (frames, h, w, c), generator=gen, device=device, dtype=dt)
+    elif pattern == "gradient":
+        yy = torch.arange(h, device=device).view(1, h, 1, 1) * (hi - 1) // h
+        xx = torch.arange(w, device=device).view(1, 1, w, 1) * (hi - 1) // w
+        nz = torch.randint(0, max(hi // 64, 1), (frames, h, w, c), generator=gen, device=device, dtype=torch.int32)
+        x = ((yy + xx) // 2 + nz).clamp_(0, hi - 1)
+    elif pattern == "blocks":
+        yy = torch.arange(h, device=device).view(1, h, 1, 1) // 16
+        xx = torch.arange(w, device=device).view(1, 1, w, 1) // 16
+        cc = torch.arange(c, device=device).view(1, 1, 1, c)
+        ff = torch.arange(frames, device=device).view(frames, 1, 1, 1)
+        x = ((yy + xx + cc + ff) % 5) * (60 if bps == 1 else 15000)
+    else:
+        raise SystemExit(f"unknown pattern {pattern}")
+    if bps == 1:
+        return x.to(torch.uint8).contiguous()
+    return x.to(torch.int32).to(torch.int16).contiguous()  # bit pattern of uint16
+
+
+def cpu_baseline(frame_np, cfg, gpu_out_np, budget_s=25.0):
+    """Time the CPU checker (oracle/ = restatement of full_TB.h:29-96) on this host.  The ONLY place bench.py
+    touches oracle/.  Sample: one frame single-threaded (what the reference does), then one frame on all cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+
+    iw, ih, c, bps, sn, sd, a, _ = cfg
+    ocfg = O.cfg(iw, ih, iw * sn // sd, ih * sn // sd, c, a, sn, sd)
+    fn = O.expected_hwc_u8 if bps == 1 else O.expected_hwc_u16
+    ncores = os.cpu_count() or 1
+    mpix = ocfg.out_w * ocfg.out_h / 1e6
+    t0 = time.perf_counter()
+    want = fn(ocfg, frame_np, ncores)
+    t_all = time.perf_counter() - t0
+    res = {"value": round(mpix / t_all, 3), "unit": "Mpix/s", "cores": ncores, "kind": "port",
+           "sample": f"1 frame {iw}x{ih}->{ocfg.out_w}x{ocfg.out_h}, oracle/ (reference software path restated), "
+                     f"{ncores} threads: {t_all:.2f} s"}
+    # single thread = the reference as written (no threading anywhere in it); bounded by the budget
+    est_single = t_all * ncores
+    if est_single < budget_s:
+        t0 = time.perf_counter()
+        fn(ocfg, frame_np, 1)
+        t1 = time.perf_counter() - t0
+        res["single_thread"] = {"value": round(mpix / t1, 3), "cores": 1, "seconds": round(t1, 2)}
+    diff = np.abs(want.astype(np.int64) - gpu_out_np.astype(np.int64))
+    res["parity_vs_gpu"] = {"max_abs_diff": int(diff.max()), "mismatching_samples": int(np.count_nonzero(diff)),
+                            "samples": int(diff.size)}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--pattern", default="noise")
+    ap.add_argument("--mode", default="lsb1", choices=["lsb1", "exact"])
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default: 16, c5: 4)")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fast"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", action="store_true",
+                    help="also time root scatter/gather of the frames over RCCL (N > 1), reported separately")
+    args = ap.parse_args()
+
+    import torch
+    import lanczos_hls_amd as L
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = CONFIGS[args.config]
+    iw, ih, c, bps, sn, sd, a, desc_txt = cfg
+    frames = args.frames or (4 if args.config == "c5" else 16)
+    mode = L.MODE_EXACT if args.mode == "exact" else L.MODE_LSB1
+    d = L.make_desc(iw, ih, c, sn, sd, a, bps, mode)
+    ctx = L.Context(local_rank)
+    ctx.force_kernel({"auto": L.KERNEL_NONE, "generic": L.KERNEL_GENERIC, "fast": L.KERNEL_FAST}[args.kernel])
+
+    x = make_frames(torch, args.pattern, frames, ih, iw, c, bps, device, seed=1234 + rank)
+    y = torch.empty((frames, d.out_h, d.out_w, c), device=device, dtype=x.dtype)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.resample_device(d, x.data_ptr(), y.data_ptr(), frames, 0, 0, stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ctx.timing_enable(True)
+    ctx.timing_read()  # reset
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    launches, main_ms, prefix_ms = ctx.timing_read()
+    ctx.timing_enable(False)
+
+    out_pix_step = frames * d.out_w * d.out_h  # per GPU
+    value = world * out_pix_step * args.steps / elapsed / 1e6
+    alg_bytes_launch = frames * (iw * ih + d.out_w * d.out_h) * c * bps
+    avg_main_s = main_ms / max(launches, 1) / 1e3
+    achieved = alg_bytes_launch / avg_main_s / 1e9 if avg_main_s > 0 else 0.0
+
+    extra = {}
+    if args.exchange and dist is not None:
+        # root-inclusive figure: rank 0 scatters every rank's input frames and gathers the outputs (RCCL)
+        reps = 3
+        xin = [torch.empty_like(x) for _ in range(world)] if rank == 0 else None
+        yout = [torch.empty_like(y) for _ in range(world)] if rank == 0 else None
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.scatter(x, xin, src=0)
+            step()
+            dist.gather(y, yout, dst=0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        extra["root_scatter_gather"] = {"value": round(world * out_pix_step * reps / float(t.item()) / 1e6, 1),
+                                        "unit": "Mpix/s", "note": "rank 0 scatters inputs / gathers outputs over RCCL"}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        f0 = x[0].cpu().numpy()
+        g0 = y[0].cpu().numpy()
+        if bps == 2:
+            f0, g0 = f0.view(np.uint16), g0.view(np.uint16)
+        cpu = cpu_baseline(f0, cfg, g0)
+
+    if rank == 0:
+        line = {
+            "metric": "output Mpixels/s", "value": round(value, 1), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc_txt, "frames_per_gpu_per_step": frames, "pattern": args.pattern,
+                       "parity_mode": args.mode, "kernel": {1: "generic", 2: "fast"}.get(ctx.last_kernel(), "?"),
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_us": round(avg_main_s * 1e6, 2), "prefix_kernel_us":
+                             round(prefix_ms / max(launches, 1) * 1e3, 2),
+                         "algorithmic_bytes_per_launch": alg_bytes_launch, "launches_timed": launches},
+            "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -346,6 +346,7 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
     g.channels = d->channels;
     g.a = d->a;
     g.in_row0 = in_row0;
+    g.in_rows = in_rows;
     g.out_row0 = row0;
     g.out_rows = rows;
     g.skip_rows = has_prefix ? p->prefix.K : 0;

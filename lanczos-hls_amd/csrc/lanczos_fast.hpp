@@ -1,12 +1,418 @@
-// lanczos_fast.hpp -- specialised kernels (integer scale, LDS-staged tiles).  Stub for bring-up.
+// lanczos_fast.hpp -- specialised fused H+V kernels for integer scales (the benchmark configurations).
+//
+// One workgroup produces a tile of TH = MR*S output rows x TWP_OUT output pixels:
+//   1. LOAD   the MR+2a-1 input rows the tile needs -> LDS (16-byte coalesced row segments, zero
+//             outside the image: a dropped tap of full_TB.h:59,72 is a zero contribution)
+//   2. HPASS  every thread owns "units" of P input pixels -> P*S output pixels of one row; the window
+//             of P+2a-1 pixels is read as aligned dwords, every byte converted once, 2a-tap fmaf chains
+//             with per-phase f32 weights held in SGPRs; results go to LDS as TRUNCATED integers (the
+//             reference's between-pass store, full_TB.h:63).
+//             The horizontal pass must be bit-exact (an error there can double up in the vertical pass),
+//             so every sample the f32 chain cannot decide is queued on an LDS worklist:
+//               - a sum within +-eps of an integer (eps = proven f32 error bound),
+//               - an integer-phase sample 1 <= v0 <= vlim, where the reference's double sum
+//                 v0 + O(1e-17) terms can land one ulp below v0 and truncate to v0-1
+//   3. FIXUP  the worklist is processed densely (one entry per lane): the exact f64 chain with the
+//             per-index double weights, separate multiply and add, ascending taps (full_TB.h:58-63)
+//   4. VPASS  every thread owns one dword column of the output and walks down the tile with a 2a-row
+//             register window; integer-phase rows are copies, the others 2a fmaf per sample.
+//             LSB1 mode: f32 result stored (within 1 LSB of the reference by the error bound).
+//             EXACT mode: rows with an undecidable sample are recomputed in f64 (wave-uniform branch).
+// Output rows < skip_rows (the in-place prefix, full_TB.h:67-77) are left to k_prefix.
 #pragma once
 #include "lanczos_kernels_common.hpp"
 #include "lanczos_taps.hpp"
 
 namespace lz {
-struct FastConsts { int dummy; };
-inline bool fast_prepare(const lanczos_desc&, const AxisTaps&, const AxisTaps&, FastConsts*) { return false; }
-inline bool fast_supports(const lanczos_desc&, const FrameGeom&) { return false; }
-inline hipError_t fast_launch(const lanczos_desc&, const FrameGeom&, const TapTables&, const FastConsts&,
-                              hipStream_t) { return hipErrorNotSupported; }
+
+constexpr int kFastMaxS = 4;
+
+struct FastConsts {
+    float wf[kFastMaxS][kMaxTaps];  // [phase][tap] f32 weights (phase 0 is the integer phase: unused)
+    float bias;                     // eps: f32-chain error bound, added to every sum
+    float near2;                    // 2*eps: fract(sum+eps) below this = undecided
+    int vlim;                       // integer-phase flip limit (0: the double chain never leaves v0)
+};
+
+template <typename T, int C_, int S_, int A_>
+struct FastCfg {
+    static constexpr int C = C_, S = S_, A = A_;
+    static constexpr int SB = (int)sizeof(T);
+    static constexpr int TAPS = 2 * A;
+    static constexpr int P = SB == 1 ? (C == 1 ? 8 : 4) : 2;  // input pixels per H unit
+    static constexpr int UPR = 32;                            // H units per tile row
+    static constexpr int TWP_IN = P * UPR;
+    static constexpr int TWP_OUT = TWP_IN * S;
+    static constexpr int TWS_OUT = TWP_OUT * C;               // output samples per tile row
+    static constexpr int TWB_OUT = TWS_OUT * SB;              // ... bytes
+    static constexpr int VEC = 4 / SB;                        // samples per V dword
+    static constexpr int NVT = TWB_OUT / 4;                   // V threads (dword columns)
+    static constexpr int NT = ((NVT + 63) / 64) * 64;         // workgroup size
+    static constexpr int MR = S == 2 ? 32 : (S == 3 ? 24 : 16);  // input rows advanced per tile
+    static constexpr int TH = MR * S;                         // output rows per tile
+    static constexpr int NR = MR + TAPS - 1;                  // H-pass rows per tile
+    static constexpr int LPB = ((A - 1) * C * SB + 15) / 16 * 16;   // left pad bytes (16-B aligned)
+    static constexpr int IN_PITCH = (LPB + TWP_IN * C * SB + A * C * SB + 15) / 16 * 16;
+    static constexpr int H_PITCH = TWB_OUT;
+    static constexpr int WIN_PX = P + TAPS - 1;               // pixels one unit reads
+    static constexpr int WIN_S = WIN_PX * C;
+    static constexpr int MIS = (LPB - (A - 1) * C * SB) % 4;  // byte offset of the window in its first dword
+    static constexpr int NW = (MIS + WIN_S * SB + 3) / 4;     // dwords per unit window
+    static constexpr int UNIT_IN_DW = P * C * SB / 4;
+    static constexpr int UNIT_OUT_S = P * S * C;
+    static constexpr int UNIT_OUT_DW = UNIT_OUT_S * SB / 4;
+    static constexpr int WIN_DW0 = (LPB - (A - 1) * C * SB - MIS) / 4;
+    static constexpr int WL_CAP = 4096;
+    static constexpr int LDS_TIN = NR * IN_PITCH;
+    static constexpr int LDS_HBUF = NR * H_PITCH;
+    static constexpr int LDS_WL = WL_CAP * 2;
+    static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL + 16;
+    static constexpr float MAXV = SB == 1 ? 255.0f : 65535.0f;
+    static_assert((P * C * SB) % 4 == 0, "unit must cover whole dwords");
+    static_assert(UNIT_OUT_S <= 64, "flag mask is 64 bits");
+    static constexpr int WL_ROW_BITS = NR <= 32 ? 5 : 6;        // worklist entry = row | sample, 16 bits
+    static constexpr int WL_SMP_BITS = 16 - WL_ROW_BITS;
+    static_assert(NR <= 64 && TWS_OUT <= (1 << WL_SMP_BITS), "worklist entry packs row | sample in 16 bits");
+    static_assert(H_PITCH % 4 == 0 && IN_PITCH % 16 == 0, "LDS pitches");
+};
+
+// sample k (static) of a dword window that starts MIS bytes into wd[0]
+template <typename T, int MIS, int NW>
+__device__ __forceinline__ unsigned win_sample(const uint32_t (&wd)[NW], int k) {
+    const int b = MIS + k * (int)sizeof(T);
+    if (sizeof(T) == 1) return (wd[b >> 2] >> (8 * (b & 3))) & 0xffu;
+    return (wd[b >> 2] >> (8 * (b & 3))) & 0xffffu;
+}
+
+template <typename T, int C, int S, int A, bool EXACT>
+__global__ __launch_bounds__((FastCfg<T, C, S, A>::NT)) void k_fast(FrameGeom g, TapTables t, FastConsts fc) {
+    using K = FastCfg<T, C, S, A>;
+    constexpr int TAPS = K::TAPS;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* tin = smem;
+    uint8_t* hbuf = smem + K::LDS_TIN;
+    uint16_t* wl = (uint16_t*)(smem + K::LDS_TIN + K::LDS_HBUF);
+    unsigned* wl_count = (unsigned*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL);
+
+    const int tid = threadIdx.x;
+    const int tiles_x = (g.out_w + K::TWP_OUT - 1) / K::TWP_OUT;
+    const int tx = blockIdx.x % tiles_x;
+    const int ty = blockIdx.x / tiles_x;
+    const int frame = blockIdx.y;
+
+    // tile geometry.  Tiles are aligned to multiples of TH in FULL-frame rows so m0 is exact.
+    const int y_tile = (g.out_row0 / K::TH + ty) * K::TH;
+    const int y_begin = y_tile > g.out_row0 ? y_tile : g.out_row0;
+    int y_end = y_tile + K::TH;
+    if (y_end > g.out_row0 + g.out_rows) y_end = g.out_row0 + g.out_rows;
+    if (y_end <= g.skip_rows || y_end <= y_begin) return;
+    const int m0 = y_tile / S;            // first input row index whose S output rows live here
+    const int r_lo = m0 - A + 1;          // LDS row 0 <-> input row r_lo (may be negative)
+    const int P0 = tx * K::TWP_IN;        // first input pixel owned by the tile
+    const int row_bytes = g.in_w * C * K::SB;
+
+    const uint8_t* in_f = g.in + (size_t)frame * g.in_frame_stride;
+    uint8_t* out_f = g.out + (size_t)frame * g.out_frame_stride;
+
+    // ------------------------------------------------------------------ 1. LOAD
+    {
+        constexpr int CPR = K::IN_PITCH / 16;
+        constexpr int NCH = K::NR * CPR;
+        const long long tile_gb0 = (long long)P0 * C * K::SB - K::LPB;
+        if (tid == 0) *wl_count = 0;
+#pragma unroll 2
+        for (int idx = tid; idx < NCH; idx += K::NT) {
+            const int row = idx / CPR, ch = idx - row * CPR;
+            const int gr = r_lo + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gr >= 0 && gr < g.in_h && gr >= g.in_row0 && gr < g.in_row0 + g.in_rows) {
+                const uint8_t* rp = in_f + (size_t)(gr - g.in_row0) * g.in_pitch;
+                const long long gb = tile_gb0 + 16 * ch;
+                if (gb >= 0 && gb + 16 <= row_bytes && (((uintptr_t)(rp + gb)) & 15) == 0) {
+                    v = *(const uint4*)(rp + gb);
+                } else if (gb + 16 > 0 && gb < row_bytes) {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (int b = 0; b < 16; b++) {
+                        const long long q = gb + b;
+                        if (q >= 0 && q < row_bytes) w[b >> 2] |= (uint32_t)rp[q] << (8 * (b & 3));
+                    }
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+            *(uint4*)(tin + row * K::IN_PITCH + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ 2. HPASS
+    {
+        constexpr int NU = K::NR * K::UPR;
+        const uint32_t* tin32 = (const uint32_t*)tin;
+        uint32_t* hbuf32 = (uint32_t*)hbuf;
+        for (int idx = tid; idx < NU; idx += K::NT) {
+            const int row = idx / K::UPR, u = idx % K::UPR;
+            uint32_t wd[K::NW];
+            const uint32_t* wp = tin32 + row * (K::IN_PITCH / 4) + K::WIN_DW0 + u * K::UNIT_IN_DW;
+#pragma unroll
+            for (int i = 0; i < K::NW; i++) wd[i] = wp[i];
+            float f[K::WIN_S];
+#pragma unroll
+            for (int k = 0; k < K::WIN_S; k++) f[k] = (float)win_sample<T, K::MIS, K::NW>(wd, k);
+
+            unsigned outv[K::UNIT_OUT_S];
+            unsigned long long mask = 0;  // bit = sample of this unit the f32 path cannot decide
+            float dmin = 1.0f;
+#pragma unroll
+            for (int q = 0; q < K::P * S; q++) {
+                const int p = q / S, ph = q % S;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const int o = q * C + c;
+                    if (ph == 0) {
+                        const unsigned v0 = win_sample<T, K::MIS, K::NW>(wd, (p + A - 1) * C + c);
+                        outv[o] = v0;
+                        if (v0 - 1u < (unsigned)fc.vlim) mask |= 1ull << o;
+                    } else {
+                        float acc = fc.bias;
+#pragma unroll
+                        for (int k = 0; k < TAPS; k++)
+                            acc = __builtin_fmaf(fc.wf[ph][k], f[(p + k) * C + c], acc);
+                        // clamp folds both the [0,max] store clamp and "no decision needed below 1 / above max"
+                        const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, K::MAXV + 0.5f);
+                        const float fl = __builtin_floorf(xc);
+                        dmin = __builtin_fminf(dmin, xc - fl);
+                        outv[o] = (unsigned)fl;
+                    }
+                }
+            }
+            if (dmin < fc.near2) {  // rare: queue every non-integer-phase sample of the unit
+#pragma unroll
+                for (int o = 0; o < K::UNIT_OUT_S; o++)
+                    if ((o / C) % S != 0) mask |= 1ull << o;
+            }
+            // store the unit (truncated integers) to the H buffer
+            uint32_t* hp = hbuf32 + row * (K::H_PITCH / 4) + u * K::UNIT_OUT_DW;
+#pragma unroll
+            for (int i = 0; i < K::UNIT_OUT_DW; i++) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int e = 0; e < K::VEC; e++) w |= outv[i * K::VEC + e] << (8 * K::SB * e);
+                hp[i] = w;
+            }
+            if (mask) {
+                const int n = __popcll(mask);
+                unsigned base = atomicAdd(wl_count, (unsigned)n);
+                const unsigned ent0 = ((unsigned)row << K::WL_SMP_BITS) | (unsigned)(u * K::UNIT_OUT_S);
+                while (mask) {
+                    const int b = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    if (base < (unsigned)K::WL_CAP) wl[base] = (uint16_t)(ent0 + b);
+                    base++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ 3. FIXUP (exact H samples)
+    {
+        const unsigned total = *wl_count;
+        const bool overflow = total > (unsigned)K::WL_CAP;
+        // If the list overflowed (pathological input) every sample of the tile is redone exactly.
+        const unsigned n = overflow ? (unsigned)(K::NR * K::TWS_OUT) : total;
+        const T* tinT = (const T*)tin;
+        T* hbufT = (T*)hbuf;
+        const int j0 = tx * K::TWS_OUT;  // first output sample column of the tile
+        for (unsigned i = tid; i < n; i += K::NT) {
+            int row, js;
+            if (overflow) {
+                row = i / K::TWS_OUT;
+                js = i % K::TWS_OUT;
+            } else {
+                const unsigned e = wl[i];
+                row = e >> K::WL_SMP_BITS;
+                js = e & ((1u << K::WL_SMP_BITS) - 1);
+            }
+            const int jg = j0 + js;
+            const int xx = jg / C, c = jg - xx * C;
+            if (xx >= g.out_w) continue;
+            const int first = xx / S - A + 1;           // == t.h_first[xx]
+            const double* w = t.h_w + (size_t)xx * TAPS;
+            const T* rp = tinT + (row * K::IN_PITCH + K::LPB) / K::SB + (first - P0) * C + c;
+            double sum = 0;
+#pragma unroll
+            for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * w[k];
+            hbufT[row * (K::H_PITCH / K::SB) + js] = store_convert<T>(sum);
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ 4. VPASS
+    if (tid < K::NVT) {
+        const uint32_t* hb = (const uint32_t*)hbuf + tid;
+        constexpr int HP = K::H_PITCH / 4;
+        const int col_b = tx * K::TWB_OUT + tid * 4;  // byte offset of this dword in the output row
+        const bool col_ok = col_b + 4 <= g.out_w * C * K::SB;
+        float win[TAPS][K::VEC];
+        uint32_t raw[TAPS];
+        auto load_row = [&](int slot, int lr) {
+            const uint32_t w = hb[lr * HP];
+            raw[slot] = w;
+#pragma unroll
+            for (int e = 0; e < K::VEC; e++)
+                win[slot][e] = (float)((w >> (8 * K::SB * e)) & (K::SB == 1 ? 0xffu : 0xffffu));
+        };
+#pragma unroll
+        for (int k = 0; k < TAPS - 1; k++) load_row(k, k);
+
+        for (int mm = 0; mm < K::MR; mm += TAPS) {
+#pragma unroll
+            for (int i = 0; i < TAPS; i++) {
+                const int ml = mm + i;          // local input row step
+                if (ml >= K::MR) break;
+                load_row((i + TAPS - 1) % TAPS, ml + TAPS - 1);
+                const int y0 = y_tile + ml * S;  // output rows y0 .. y0+S-1 have floor(y/S) = m0+ml
+#pragma unroll
+                for (int ph = 0; ph < S; ph++) {
+                    const int y = y0 + ph;
+                    uint32_t packed;
+                    bool undecided = false;
+                    if (ph == 0) {
+                        packed = raw[(i + A - 1) % TAPS];
+                        if (EXACT) {
+#pragma unroll
+                            for (int e = 0; e < K::VEC; e++) {
+                                const unsigned v0 = (packed >> (8 * K::SB * e)) & (K::SB == 1 ? 0xffu : 0xffffu);
+                                undecided |= (v0 - 1u < (unsigned)fc.vlim);
+                            }
+                        }
+                    } else {
+                        packed = 0;
+#pragma unroll
+                        for (int e = 0; e < K::VEC; e++) {
+                            float acc = fc.bias;
+#pragma unroll
+                            for (int k = 0; k < TAPS; k++)
+                                acc = __builtin_fmaf(fc.wf[ph][k], win[(i + k) % TAPS][e], acc);
+                            const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, K::MAXV + 0.5f);
+                            const float fl = __builtin_floorf(xc);
+                            if (EXACT) undecided |= (xc - fl) < fc.near2;
+                            packed |= (unsigned)fl << (8 * K::SB * e);
+                        }
+                    }
+                    if (EXACT) {
+                        if (__any(undecided)) {  // wave-uniform: redo this row's dword in f64 (full_TB.h:71-75)
+                            const double* wv = t.v_w + (size_t)(y < g.out_h ? y : g.out_h - 1) * TAPS;
+                            packed = 0;
+#pragma unroll
+                            for (int e = 0; e < K::VEC; e++) {
+                                double sum = 0;
+#pragma unroll
+                                for (int k = 0; k < TAPS; k++) sum += (double)win[(i + k) % TAPS][e] * wv[k];
+                                packed |= (unsigned)store_convert<T>(sum) << (8 * K::SB * e);
+                            }
+                        }
+                    }
+                    if (col_ok && y >= y_begin && y < y_end && y >= g.skip_rows) {
+                        uint32_t* op = (uint32_t*)(out_f + (size_t)(y - g.out_row0) * g.out_pitch + col_b);
+                        *op = packed;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- host side
+inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTaps& V, FastConsts* fc) {
+    const int S = d.scale_n, a = d.a, taps = 2 * a;
+    if (d.scale_d != 1 || S < 2 || S > kFastMaxS) return false;
+    // phase weights from an interior output index (all 2a taps in range), either axis will do
+    const AxisTaps* ax = nullptr;
+    for (const AxisTaps* cand : {&H, &V})
+        if (cand->in_n >= 2 * a + 2 && cand->out_n > S * a + S) ax = cand;
+    if (!ax) return false;
+    const double maxv = d.bytes_per_sample == 1 ? 255.0 : 65535.0;
+    double eps = 0;
+    for (int ph = 0; ph < kFastMaxS; ph++)
+        for (int k = 0; k < kMaxTaps; k++) fc->wf[ph][k] = 0.0f;
+    for (int ph = 0; ph < S; ph++) {
+        const int o = S * a + ph;
+        const double* w = &ax->w[(size_t)o * taps];
+        for (int k = 0; k < taps; k++) fc->wf[ph][k] = (float)w[k];
+        if (ph != 0) {
+            const double e = f32_chain_error_bound(w, taps, maxv);
+            if (e > eps) eps = e;
+        }
+    }
+    // per-index weights differ from the phase weights by the rounding of x = o/S (a few ulp of x):
+    // far below the f32 slack, but count it: |dw| <= |L'| * ulp(x) <= 4 * 2^-52 * out_n
+    eps += 4.0 * 2.220446049250313e-16 * (H.out_n > V.out_n ? H.out_n : V.out_n) * maxv * taps;
+    fc->bias = (float)eps;
+    fc->near2 = (float)(2.0 * eps) * 1.0001f;
+    fc->vlim = integer_phase_flip_limit(&ax->w[(size_t)(S * a) * taps], a, (int)maxv);
+    if (eps > 0.2) return false;  // f32 cannot even guarantee +-1 LSB
+    return true;
+}
+
+template <typename T, int C, int S, int A>
+inline hipError_t fast_launch_t(const lanczos_desc& d, const FrameGeom& g, const TapTables& t,
+                                const FastConsts& fc, hipStream_t stream) {
+    using K = FastCfg<T, C, S, A>;
+    const int tiles_x = (g.out_w + K::TWP_OUT - 1) / K::TWP_OUT;
+    const int ty0 = g.out_row0 / K::TH;
+    const int ty1 = (g.out_row0 + g.out_rows - 1) / K::TH;
+    dim3 grid(tiles_x * (ty1 - ty0 + 1), g.frames);
+    static bool attr_done[2][64] = {};
+    const bool exact = d.mode == LANCZOS_MODE_EXACT;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!attr_done[exact][dev]) {
+        hipError_t e = exact ? hipFuncSetAttribute((const void*)k_fast<T, C, S, A, true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES)
+                             : hipFuncSetAttribute((const void*)k_fast<T, C, S, A, false>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done[exact][dev] = true;
+    }
+    if (exact)
+        hipLaunchKernelGGL((k_fast<T, C, S, A, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
+    else
+        hipLaunchKernelGGL((k_fast<T, C, S, A, false>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
+    return hipGetLastError();
+}
+
+// the instantiated configurations: (sample bytes, channels, scale, a)
+#define LZ_FAST_CONFIGS(X) \
+    X(uint8_t, 3, 2, 3)    \
+    X(uint8_t, 3, 3, 3)    \
+    X(uint8_t, 3, 2, 2)    \
+    X(uint8_t, 3, 2, 4)    \
+    X(uint8_t, 4, 2, 4)    \
+    X(uint8_t, 4, 2, 3)    \
+    X(uint8_t, 1, 2, 3)    \
+    X(uint16_t, 4, 2, 4)   \
+    X(uint16_t, 3, 2, 3)
+
+inline bool fast_supports(const lanczos_desc& d, const FrameGeom& g) {
+    if (d.scale_d != 1) return false;
+    if (g.out_pitch % 4 != 0 || (((uintptr_t)g.out) & 3) != 0 || (g.out_frame_stride & 3) != 0) return false;
+#define X(T, C, S, A) \
+    if (d.bytes_per_sample == (int)sizeof(T) && d.channels == C && d.scale_n == S && d.a == A) return true;
+    LZ_FAST_CONFIGS(X)
+#undef X
+    return false;
+}
+
+inline hipError_t fast_launch(const lanczos_desc& d, const FrameGeom& g, const TapTables& t, const FastConsts& fc,
+                              hipStream_t stream) {
+#define X(T, C, S, A)                                                                               \
+    if (d.bytes_per_sample == (int)sizeof(T) && d.channels == C && d.scale_n == S && d.a == A)      \
+        return fast_launch_t<T, C, S, A>(d, g, t, fc, stream);
+    LZ_FAST_CONFIGS(X)
+#undef X
+    return hipErrorNotSupported;
+}
+
 }  // namespace lz

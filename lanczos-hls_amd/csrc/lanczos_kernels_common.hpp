@@ -17,7 +17,7 @@ struct FrameGeom {
     int in_pitch, out_pitch;
     int in_w, in_h, out_w, out_h;  // full frame
     int channels, a;
-    int in_row0;          // full-frame index of the first row behind `in`
+    int in_row0, in_rows; // full-frame index of the first row behind `in`, and how many rows it holds
     int out_row0, out_rows;  // strip to produce
     int skip_rows;        // output rows < skip_rows are left to the in-place prefix kernel
     int frames;

@@ -92,7 +92,15 @@ SHAPES = [
     (200, 120, 3, 2, 1, 3), (160, 90, 3, 3, 1, 3), (128, 96, 3, 2, 1, 2), (96, 64, 4, 2, 1, 4),
     (150, 100, 3, 4, 3, 3), (120, 80, 1, 2, 1, 3), (90, 60, 4, 3, 1, 2), (100, 75, 3, 3, 2, 3),
     (64, 33, 1, 5, 2, 4), (515, 131, 3, 2, 1, 3), (333, 77, 3, 3, 1, 3),
+    # served by the specialised kernels: several tiles wide/tall, ragged right and bottom edges
+    (514, 131, 3, 2, 1, 3), (320, 99, 3, 3, 1, 3), (700, 50, 3, 2, 1, 3), (130, 300, 3, 2, 1, 3),
+    (260, 200, 4, 2, 1, 4), (260, 200, 1, 2, 1, 3), (258, 70, 3, 2, 1, 2), (258, 70, 3, 2, 1, 4),
+    (200, 90, 4, 2, 1, 3),
 ]
+FAST_SHAPES = {(200, 120, 3, 2, 1, 3), (160, 90, 3, 3, 1, 3), (128, 96, 3, 2, 1, 2), (96, 64, 4, 2, 1, 4),
+               (120, 80, 1, 2, 1, 3), (514, 131, 3, 2, 1, 3), (320, 99, 3, 3, 1, 3), (700, 50, 3, 2, 1, 3),
+               (130, 300, 3, 2, 1, 3), (260, 200, 4, 2, 1, 4), (260, 200, 1, 2, 1, 3), (258, 70, 3, 2, 1, 2),
+               (258, 70, 3, 2, 1, 4), (200, 90, 4, 2, 1, 3)}
 
 
 @pytest.mark.parametrize("mode", [L.MODE_EXACT, L.MODE_LSB1])
@@ -103,6 +111,8 @@ def test_oracle_parity_medium(ctx, pattern, mode):
         want = _oracle(img, sn, sd, a)
         got = ctx.resample(img, sn, sd, a, mode)
         _cmp(got, want, mode, f"{pattern} {w}x{h}x{c} {sn}/{sd} a={a}")
+        want_family = L.KERNEL_FAST if (w, h, c, sn, sd, a) in FAST_SHAPES else L.KERNEL_GENERIC
+        assert ctx.last_kernel() == want_family, (w, h, c, sn, sd, a, ctx.last_kernel())
 
 
 def test_tiny_images_all_taps_clipped(ctx):
