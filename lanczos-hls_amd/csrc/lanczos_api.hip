@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -16,6 +17,7 @@
 
 #include "../../include/lanczos_hip.h"
 #include "lanczos_fast.hpp"
+#include "lanczos_march.hpp"
 #include "lanczos_generic.hpp"
 #include "lanczos_kernels_common.hpp"
 #include "lanczos_taps.hpp"
@@ -56,7 +58,9 @@ struct lanczos_ctx {
     int ev_used = 0;
     int launches = 0;
     double main_ms = 0, prefix_ms = 0;
+    void* stamp_buf = nullptr;
 };
+static constexpr size_t kStampBytes = 16384 * 8 * 6 * 8;
 
 namespace {
 
@@ -257,6 +261,23 @@ int lanczos_destroy(lanczos_ctx* ctx) {
         if (kv.second->dev_block) (void)hipFree(kv.second->dev_block);
         delete kv.second;
     }
+    if (ctx->stamp_buf) {
+        std::vector<unsigned long long> h(kStampBytes / 8);
+        if (hipMemcpy(h.data(), ctx->stamp_buf, kStampBytes, hipMemcpyDeviceToHost) == hipSuccess) {
+            double sum[5] = {0, 0, 0, 0, 0}, ticks = 0;
+            long n = 0;
+            for (size_t i = 0; i + 5 < h.size(); i += 6)
+                if (h[i + 5]) {
+                    for (int k = 0; k < 5; k++) sum[k] += (double)h[i + k];
+                    ticks += (double)h[i + 5];
+                    n++;
+                }
+            if (n)
+                fprintf(stderr, "STAMP waves=%ld ticks/wave=%.1f cycles/tick: issue=%.0f hpass=%.0f commit=%.0f vpass=%.0f barrier=%.0f\n",
+                        n, ticks / n, sum[0] / ticks, sum[1] / ticks, sum[2] / ticks, sum[3] / ticks, sum[4] / ticks);
+        }
+        (void)hipFree(ctx->stamp_buf);
+    }
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
@@ -351,6 +372,18 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
     g.out_rows = rows;
     g.skip_rows = has_prefix ? p->prefix.K : 0;
     g.frames = frames;
+    {
+        static const int dbg = getenv("LANCZOS_DEBUG_SKIP") ? atoi(getenv("LANCZOS_DEBUG_SKIP")) : 0;
+        g.debug_skip = dbg;
+        // LANCZOS_STAMP=1: diagnostic kernel build that sums s_memtime deltas per phase; results are dumped to
+        // stderr by lanczos_destroy (never used by tests or the benchmark numbers)
+        static const bool stamp = getenv("LANCZOS_STAMP") && atoi(getenv("LANCZOS_STAMP")) != 0;
+        g.stamps = nullptr;
+        if (stamp) {
+            if (!ctx->stamp_buf) (void)hipMalloc(&ctx->stamp_buf, kStampBytes), (void)hipMemset(ctx->stamp_buf, 0, kStampBytes);
+            g.stamps = (unsigned long long*)ctx->stamp_buf;
+        }
+    }
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     if (ctx->timing) {
@@ -374,7 +407,10 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
                     lz::fast_supports(*d, g);
     if (ctx->force == LANCZOS_KERNEL_FAST && !use_fast) return LANCZOS_ERR_UNSUPPORTED;
     if (use_fast) {
-        hipError_t e = lz::fast_launch(*d, g, p->dev, p->fast, stream);
+        // LANCZOS_TILE_KERNEL=1 selects the older tile-per-workgroup kernel (kept for A/B measurements)
+        static const bool use_tile = getenv("LANCZOS_TILE_KERNEL") && atoi(getenv("LANCZOS_TILE_KERNEL")) != 0;
+        hipError_t e = (use_tile || !lz::march_supports(g)) ? lz::fast_launch(*d, g, p->dev, p->fast, stream)
+                                                             : lz::march_launch(*d, g, p->dev, p->fast, stream);
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
             return LANCZOS_ERR_HIP;

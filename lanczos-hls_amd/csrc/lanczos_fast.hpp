@@ -22,6 +22,8 @@
 //             EXACT mode: rows with an undecidable sample are recomputed in f64 (wave-uniform branch).
 // Output rows < skip_rows (the in-place prefix, full_TB.h:67-77) are left to k_prefix.
 #pragma once
+#include <cmath>
+
 #include "lanczos_kernels_common.hpp"
 #include "lanczos_taps.hpp"
 
@@ -36,6 +38,8 @@ struct FastConsts {
     float vbias_rne;                // eps - 0.5: bias under which the RNE byte convert is floor(sum + eps)
     float near2;                    // 2*eps: fract(sum+eps) below this = undecided
     int vlim;                       // integer-phase flip limit (0: the double chain never leaves v0)
+    int tight;                      // 1: the only non-negligible negative integer-phase taps sit at +-2 pixels and
+                                    //    are < 2^-55, so neighbours <= 2*v0 prove that v0 stays (see fast_prepare)
 };
 
 // per-configuration tile shape: MR input rows advanced per tile, NGRP vertical thread groups in the V pass
@@ -497,6 +501,23 @@ inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTap
     fc->near2 = (float)(2.0 * eps) * 1.0001f;
     fc->vlim = integer_phase_flip_limit(fc->wi, a, (int)maxv);
     if (fc->vlim >= (d.bytes_per_sample == 1 ? 126 : 32766)) return false;  // SWAR test needs vlim < half range
+    // Tight filter precondition.  Lower-bound chain (integer_phase_flip_limit): v0 can only be left through a
+    // negative tiny term n*|w| reaching half the spacing below v0, which is >= 2^-54 * v0.  If the negative taps
+    // are exactly d = +2 and d = -2 with |w| < 2^-55, then n <= 2*v0 gives n*|w| < 2^-54 * v0: v0 stays.
+    {
+        bool ok = a >= 3;
+        const double negl = std::ldexp(1.0, -70) / maxv;  // contributes < 2^-70: cannot reach any half spacing >= 2^-54
+        for (int k = 0; k < taps && ok; k++) {
+            const int dist = a - 1 - k;                    // x - i of this tap
+            const double w = fc->wi[k];
+            if (dist == 2 || dist == -2) {
+                if (!(w < 0 && -w < std::ldexp(1.0, -55) * (1.0 - 1e-9))) ok = false;
+            } else if (w < 0 && -w > negl) {
+                ok = false;
+            }
+        }
+        fc->tight = ok ? 1 : 0;
+    }
     if (eps > 0.2) return false;  // f32 cannot even guarantee +-1 LSB
     return true;
 }

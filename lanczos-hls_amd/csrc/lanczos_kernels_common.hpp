@@ -21,6 +21,8 @@ struct FrameGeom {
     int out_row0, out_rows;  // strip to produce
     int skip_rows;        // output rows < skip_rows are left to the in-place prefix kernel
     int frames;
+    unsigned long long* stamps;  // diagnostic builds only: per-wave cycle sums (see k_march STAMP)
+    int debug_skip;       // ablation bits for profiling builds (0 in production): 1 H-pass, 2 fix-up, 4 V-pass, 8 stores, 16 loads
 };
 
 struct TapTables {

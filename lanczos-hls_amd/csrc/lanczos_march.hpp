@@ -1,0 +1,599 @@
+// lanczos_march.hpp -- the production kernel: a workgroup MARCHES down a column strip of the frame.
+//
+// This is the MI355X replacement for the reference's strip scheduler + workers + cyclic line buffer
+// (process_channel lanczos.cpp:68-83, ColWorkers/RowWorkers worker.cpp:134-284, CyclicBuffer
+// cyclic_buffer.h:4-69): a ring of horizontally-resampled rows lives in LDS and is advanced MS input rows
+// per "tick"; nothing but the input and output frames ever touches HBM.
+//
+// Workgroup = one strip of TWP_OUT output pixels x one vertical chunk of the frame.  ONE barrier per tick;
+// between two barriers every wave runs, back to back and independent of the other waves:
+//   PREFETCH  one 16-byte buffer load per lane of the input rows two ticks ahead (out-of-image lanes read
+//             zeros through the descriptor's range check: a dropped tap is a zero contribution)
+//   HPASS     tick t+1: one unit (P input pixels -> P*S output pixels of one row) per thread from the LDS
+//             input rows: aligned dword reads, v_cvt_f32_ubyteN, 2a-tap fmaf chains with SGPR weights,
+//             v_perm_b32 / v_cvt_pk_u8_f32 packing, truncated integers into the LDS ring (the reference's
+//             between-pass store, full_TB.h:63)
+//   FIXUP     samples the f32 chain cannot decide are compacted per WAVE (ballot + mbcnt, no atomics) into a
+//             wave-private LDS list and redone densely with the exact f64 chain (full_TB.h:58-63):
+//               - a sum within +-eps of an integer (eps = proven f32 error bound)
+//               - an integer-phase sample whose double sum v0 + O(1e-17) may truncate to v0-1:
+//                 1 <= v0 <= vlim and a +-2 neighbour brighter than 2*v0 (SWAR tests on the packed bytes)
+//   VPASS     tick t: one dword column per thread, 2a-row register window over the ring; integer-phase rows
+//             are dword copies, the others 2a fmaf + one v_cvt_pk_u8_f32 per sample; buffer stores with the
+//             row offset in the scalar operand
+// ~40 KiB of LDS per workgroup: 3-4 workgroups (18-24 waves) per CU.
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+
+#include "lanczos_fast.hpp"
+
+namespace lz {
+
+template <typename T, int C, int S, int A>
+struct MarchShape {
+    static constexpr int NGRP = 2;                                  // V groups (whole waves each)
+    static constexpr int MS = 2 * A * NGRP;                         // input rows per tick
+};
+template <int A>
+struct MarchShape<uint8_t, 3, 3, A> {  // 288 dword columns: one V group of 4.5 waves
+    static constexpr int NGRP = 1;
+    static constexpr int MS = 12;
+};
+
+template <typename T, int C_, int S_, int A_>
+struct MarchCfg {
+    using F = FastCfg<T, C_, S_, A_>;  // unit geometry is shared with the tile kernel
+    static constexpr int C = C_, S = S_, A = A_;
+    static constexpr int SB = F::SB, TAPS = F::TAPS, P = F::P, UPR = F::UPR;
+    static constexpr int NGRP = MarchShape<T, C, S, A>::NGRP;
+    static constexpr int MS = MarchShape<T, C, S, A>::MS;
+    static constexpr int MRG = MS / NGRP;
+    static constexpr int NVT = F::NVT;
+    static constexpr int NU = MS * UPR;                              // H units per tick
+    static constexpr int NT_V = NVT * NGRP;
+    static constexpr int NT = (((NT_V > NU ? NT_V : NU) + 63) / 64) * 64;
+    static constexpr int NWAVES = NT / 64;
+    static constexpr int RS = (2 * MS + TAPS - 1) <= 32 ? 32 : 64;   // ring rows: two ticks + the window
+    static constexpr int IN_PITCH = F::IN_PITCH, H_PITCH = F::H_PITCH, CPR = F::CPR;
+    static constexpr int NCH = MS * CPR;                             // 16-byte chunks of one tick's input
+    static constexpr int LOAD_IT = (NCH + NT - 1) / NT;
+    static constexpr int TIN_BYTES = LOAD_IT * NT * 16;              // >= MS*IN_PITCH: every lane commits a chunk
+    static constexpr int WLW = 64 * F::UNIT_IN_DW;                   // worklist entries per wave: one round of candidates
+    static constexpr int LDS_TIN = 2 * TIN_BYTES;                    // double buffered
+    static constexpr int LDS_HBUF = RS * H_PITCH;
+    static constexpr int LDS_WL = NWAVES * WLW * 2;
+    static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL;
+    static constexpr int NNI = F::UNIT_OUT_S - P * C;                // non-integer-phase samples of a unit
+    static_assert(MS % NGRP == 0, "V groups split a tick evenly");
+    static_assert(NGRP == 1 || NVT % 64 == 0, "V groups must be whole waves");
+    static_assert(RS >= 2 * MS + TAPS - 1, "ring holds two ticks plus the window");
+    static_assert(64 % UPR == 0, "a wave covers whole unit rows");
+    static_assert(F::UNIT_OUT_S <= 64 && MS <= 32 && UPR <= 32, "worklist entry = row:5 | unit:5 | sample:6");
+};
+
+template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false>
+__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) void k_march(FrameGeom g, TapTables t, FastConsts fc,
+                                                                      int chunk_rows) {
+    using K = MarchCfg<T, C, S, A>;
+    using F = typename K::F;
+    constexpr int TAPS = K::TAPS, SB = K::SB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* hbuf = smem + K::LDS_TIN;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    uint16_t* wlw = (uint16_t*)(smem + K::LDS_TIN + K::LDS_HBUF) + wave * K::WLW;  // this wave's list
+
+    const int strips = (g.out_w + F::TWP_OUT - 1) / F::TWP_OUT;
+    const int tx = blockIdx.x % strips;
+    const int chunk = blockIdx.x / strips;
+    const int frame = blockIdx.y;
+
+    // rows: m = floor(y/S) is the input row an output row hangs on.  This workgroup owns m in [m_b, m_e).
+    const int y_lo = g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows;  // first output row stored at all
+    const int y_hi = g.out_row0 + g.out_rows;                               // one past the last
+    const int m_b = y_lo / S + chunk * chunk_rows;
+    int m_e = m_b + chunk_rows;
+    if (m_e > (y_hi - 1) / S + 1) m_e = (y_hi - 1) / S + 1;
+    if (m_b >= m_e) return;
+    const int hb = m_b - (A - 1);           // first H row (= input row) this chunk needs
+    const int h_last = m_e - 1 + A;         // last one
+    const int ticks = (h_last - hb + 1 + K::MS - 1) / K::MS;
+
+    const int P0 = tx * F::TWP_IN;          // first input pixel owned by the strip
+    const int row_bytes = g.in_w * C * SB;
+    const uint8_t* in_f = g.in + (size_t)frame * g.in_frame_stride;
+    uint8_t* out_f = g.out + (size_t)frame * g.out_frame_stride;
+    const int gr_min = g.in_row0 > 0 ? g.in_row0 : 0;
+    const int gr_max = (g.in_row0 + g.in_rows < g.in_h ? g.in_row0 + g.in_rows : g.in_h) - 1;
+    const int tile_gb0 = P0 * C * SB - F::LPB;  // byte offset in the input row of LDS column 0
+
+    // ---- input rows of one tick -> registers -> LDS.  Rows are 16-byte multiples (checked on the host), so a
+    // chunk is never partly inside the image; outside lanes get an out-of-range offset and read zeros.
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(in_f), 0, (unsigned)(g.in_rows * g.in_pitch), 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 pre[K::LOAD_IT];
+    auto issue_loads = [&](int tick) {
+#pragma unroll
+        for (int it = 0; it < K::LOAD_IT; it++) {
+            const int idx = tid + it * K::NT;
+            const int row = idx / K::CPR, ch = idx - row * K::CPR;
+            const int gr = hb + tick * K::MS + row;
+            const int gb = tile_gb0 + 16 * ch;
+            const bool ok = !(g.debug_skip & 16) && tick < ticks && idx < K::NCH && gr >= gr_min && gr <= gr_max &&
+                            gr <= h_last && gb >= 0 && gb < row_bytes;
+            const unsigned off = ok ? (unsigned)((gr - g.in_row0) * g.in_pitch + gb) : 0xffffffffu;
+            pre[it] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);
+        }
+    };
+    auto commit_loads = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < K::LOAD_IT; it++)
+            *(u32x4*)(smem + buf * K::TIN_BYTES + (tid + it * K::NT) * 16) = pre[it];
+    };
+
+    // ---- constants kept in SGPRs for the whole march
+    float wv[S][TAPS];
+#pragma unroll
+    for (int ph = 1; ph < S; ph++)
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) {
+            wv[ph][k] = fc.wf[ph][k];
+            asm volatile("" : "+s"(wv[ph][k]));
+        }
+    constexpr uint32_t HALF = SB == 1 ? 0x80u : 0x8000u;
+    constexpr uint32_t LOW = SB == 1 ? 0x7f7f7f7fu : 0x7fff7fffu;
+    constexpr uint32_t TOP = SB == 1 ? 0x80808080u : 0x80008000u;
+    const uint32_t addc1 = (uint32_t)fc.vlim < HALF - 1 ? HALF - 1 - (uint32_t)fc.vlim : 0;
+    const uint32_t addc = SB == 1 ? addc1 * 0x01010101u : addc1 * 0x00010001u;
+
+    // =================================================================== HPASS + FIXUP of one tick
+    auto hpass = [&](int tick) {
+        const uint8_t* tin = smem + (tick & 1) * K::TIN_BYTES;
+        const int h0 = hb + tick * K::MS;           // first H row of the tick
+        const int row = tid / K::UPR, u = tid % K::UPR;
+        const bool unit_ok = tid < K::NU && h0 + row <= h_last && !(g.debug_skip & 1);
+        uint32_t im = 0;      // undecided integer-phase samples: bit (8*e*SB + i) <-> own input sample i*VEC + e
+        bool near = false;    // some non-integer-phase sample of the unit is within eps of an integer
+        if (unit_ok) {
+            const uint32_t* tin32 = (const uint32_t*)tin;
+            uint32_t wd[F::NW];
+            const uint32_t* wp = tin32 + row * (K::IN_PITCH / 4) + F::WIN_DW0 + u * F::UNIT_IN_DW;
+#pragma unroll
+            for (int i = 0; i < F::NW; i++) wd[i] = wp[i];
+            float f[F::WIN_S];
+#pragma unroll
+            for (int k = 0; k < F::WIN_S; k++) f[k] = (float)win_sample<T, F::MIS, F::NW>(wd, k);
+
+            float xb[F::UNIT_OUT_S];
+            float dmin = 1.0f;
+#pragma unroll
+            for (int q = 0; q < K::P * S; q++) {
+                const int p = q / S, ph = q % S;
+                if (ph == 0) continue;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    float acc = fc.bias;
+#pragma unroll
+                    for (int k = 0; k < TAPS; k++) acc = __builtin_fmaf(wv[ph][k], f[(p + k) * C + c], acc);
+                    // below 1 / above max the store clamps: nothing to decide there
+                    const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, F::MAXV + 0.5f);
+                    const float fl = __builtin_floorf(xc);
+                    dmin = __builtin_fminf(dmin, xc - fl);
+                    xb[q * C + c] = fl;
+                }
+            }
+            near = dmin < fc.near2;
+            const int slot = (h0 + row - hb) & (K::RS - 1);
+            uint32_t* hp = (uint32_t*)hbuf + slot * (K::H_PITCH / 4) + u * F::UNIT_OUT_DW;
+            uint32_t ow[F::UNIT_OUT_DW];
+#pragma unroll
+            for (int i = 0; i < F::UNIT_OUT_DW; i++) {
+                uint32_t w = 0;
+                if (SB == 1) {
+                    // integer-phase samples are copies of input bytes: one v_perm_b32 when they come from <= 2
+                    // window dwords; the computed ones are inserted with the saturating byte convert
+                    int src[4], d0 = -1, d1 = -1;
+                    bool any_raw = false, perm_ok = true;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int o = i * 4 + e, q = o / C, c = o % C;
+                        src[e] = -1;
+                        if (q % S == 0) {
+                            const int b = F::MIS + ((q / S + A - 1) * C + c);
+                            src[e] = b;
+                            any_raw = true;
+                            const int dw = b >> 2;
+                            if (d0 < 0 || d0 == dw) d0 = dw;
+                            else if (d1 < 0 || d1 == dw) d1 = dw;
+                            else perm_ok = false;
+                        }
+                    }
+                    if (any_raw) {
+                        if (perm_ok) {
+                            uint32_t sel = 0;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                uint32_t s = 0x0c;  // constant 0
+                                if (src[e] >= 0) s = ((src[e] >> 2) == d0 ? 0 : 4) + (src[e] & 3);
+                                sel |= s << (8 * e);
+                            }
+                            w = __builtin_amdgcn_perm(wd[d1 < 0 ? d0 : d1], wd[d0], sel);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                if (src[e] >= 0) w |= ((wd[src[e] >> 2] >> (8 * (src[e] & 3))) & 0xffu) << (8 * e);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int o = i * 4 + e;
+                        if ((o / C) % S != 0) w = __builtin_amdgcn_cvt_pk_u8_f32(xb[o], e, w);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int o = i * 2 + e, q = o / C, c = o % C;
+                        const unsigned sv = (q % S == 0) ? win_sample<T, F::MIS, F::NW>(wd, (q / S + A - 1) * C + c)
+                                                         : (unsigned)xb[o];
+                        w |= sv << (16 * e);
+                    }
+                }
+                ow[i] = w;
+            }
+            // widest aligned LDS stores the unit allows
+            if (F::UNIT_OUT_DW % 2 == 0) {
+#pragma unroll
+                for (int i = 0; i + 1 < F::UNIT_OUT_DW; i += 2) *(uint2*)(hp + i) = make_uint2(ow[i], ow[i + 1]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < F::UNIT_OUT_DW; i++) hp[i] = ow[i];
+            }
+            // integer-phase candidates (SWAR on the unit's own input dwords)
+            if (fc.vlim > 0) {
+                constexpr int OWN_B0 = F::MIS + (A - 1) * C * SB;   // window byte offset of the own pixels
+                constexpr int OWN_DW0 = OWN_B0 / 4;
+                static_assert(OWN_B0 % 4 == 0 && F::UNIT_IN_DW <= 7, "own pixels are whole dwords");
+                uint32_t loose[F::UNIT_IN_DW], any = 0;
+#pragma unroll
+                for (int i = 0; i < F::UNIT_IN_DW; i++) {
+                    loose[i] = swar_in_1_vlim<SB>(wd[OWN_DW0 + i], addc);  // 1 <= v0 <= vlim
+                    any |= loose[i];
+                }
+                if (!fc.tight) {
+#pragma unroll
+                    for (int i = 0; i < F::UNIT_IN_DW; i++) im |= (loose[i] >> (8 * SB - 1)) << i;
+                } else if (__any(any != 0)) {
+                    // tight filter: the chain can only leave v0 through the negative taps at +-2 pixels; if both
+                    // neighbours are <= 2*v0 (< 3.44 * 2^ceil(log2 v0), the proven bound) v0 stays
+#pragma unroll
+                    for (int i = 0; i < F::UNIT_IN_DW; i++) {
+                        auto window_word = [&](int bo) -> uint32_t {  // 4 bytes at window byte offset bo (static)
+                            return (bo & 3) == 0 ? wd[bo >> 2]
+                                                 : __builtin_amdgcn_alignbyte(wd[(bo >> 2) + 1], wd[bo >> 2], bo & 3);
+                        };
+                        const uint32_t x = wd[OWN_DW0 + i];
+                        const uint32_t c2 = ((x & LOW) << 1) | TOP;
+                        const uint32_t nm = window_word(OWN_B0 + 4 * i - 2 * C * SB);
+                        const uint32_t np = window_word(OWN_B0 + 4 * i + 2 * C * SB);
+                        const uint32_t pm = (c2 - (nm & LOW)) & ~nm;   // top bit: n(-2) <= 2*v0
+                        const uint32_t pp = (c2 - (np & LOW)) & ~np;   // top bit: n(+2) <= 2*v0
+                        const uint32_t tight = loose[i] & ~(pm & pp) & TOP;
+                        im |= (tight >> (8 * SB - 1)) << i;
+                    }
+                }
+            }
+        }
+        if (g.debug_skip & 32) {
+            im = 0;
+            near = false;
+        }
+
+        // ---- wave-private compaction of the undecided samples, then the exact chain, densely
+        if (__any(im != 0 || near) && !(g.debug_skip & 2)) {
+            int cnt = 0;  // uniform
+            auto flush = [&]() {
+                const T* tinT = (const T*)tin;
+                T* hbufT = (T*)hbuf;
+                for (int i = lane; i < cnt; i += 64) {
+                    const unsigned e = wlw[i];
+                    const int erow = e >> 11, eu = (e >> 6) & 31, o = e & 63;
+                    const int q = o / C, c = o - q * C;          // output pixel / channel inside the unit
+                    const int xl = eu * (K::P * S) + q;          // output pixel inside the strip
+                    const int xx = tx * F::TWP_OUT + xl;
+                    if (xx >= g.out_w) continue;
+                    const int fl = xl / S;                        // floor(x) - P0
+                    const T* rp = tinT + (erow * K::IN_PITCH + F::LPB) / SB + (fl - A + 1) * C + c;
+                    double sum = 0;
+                    if (xl - fl * S == 0) {                       // integer phase: the same weights everywhere
+#pragma unroll
+                        for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * fc.wi[k];
+                    } else {
+                        const double* w = t.h_w + (size_t)xx * TAPS;
+#pragma unroll
+                        for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * w[k];
+                    }
+                    const int slot = (h0 + erow - hb) & (K::RS - 1);
+                    hbufT[slot * (K::H_PITCH / SB) + xl * C + c] = store_convert<T>(sum);
+                }
+                cnt = 0;
+            };
+            const unsigned ent0 = ((unsigned)row << 11) | ((unsigned)u << 6);
+            auto append = [&](bool flag, int o) {  // o wave-uniform: output sample of the unit
+                const unsigned long long m = __ballot(flag);
+                if (m == 0) return;
+                if (flag)
+                    wlw[cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] =
+                        (uint16_t)(ent0 + o);
+                cnt += __popcll(m);
+            };
+            // integer-phase candidates: one round per byte/halfword lane e of the own dwords (runtime loop so the
+            // exact chain in flush() is not replicated per sample position); a round adds <= 64*UNIT_IN_DW entries
+#pragma unroll 1
+            for (int e = 0; e < F::VEC; e++) {
+#pragma unroll
+                for (int i = 0; i < F::UNIT_IN_DW; i++) {
+                    const int si = i * F::VEC + e, p = si / C, c = si - p * C;  // own input sample -> its integer phase
+                    append((im >> (8 * SB * e + i)) & 1, (p * S) * C + c);
+                }
+                if (cnt > 0) flush();
+            }
+            if (__any(near)) {  // rare: every non-integer-phase sample of the flagged units
+#pragma unroll 1
+                for (int o = 0; o < F::UNIT_OUT_S; o++) {
+                    if ((o / C) % S == 0) continue;
+                    append(near, o);
+                    if (cnt > K::WLW - 64) flush();
+                }
+                if (cnt > 0) flush();
+            }
+        }
+    };
+
+    // =================================================================== VPASS of one tick
+    const int grp = K::NGRP == 1 ? (tid < K::NVT ? 0 : 1) : wave * 64 / K::NVT;
+    const int col = tid - grp * K::NVT;
+    const unsigned col_b = (unsigned)(tx * F::TWB_OUT + col * 4);
+    const bool col_ok = grp < K::NGRP && col_b + 4 <= (unsigned)(g.out_w * C * SB);
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc(out_f, 0, (unsigned)(g.out_rows * g.out_pitch), 0x00020000);
+    const float vbias = (SB == 1 && !EXACT) ? fc.vbias_rne : fc.bias;
+
+    auto vpass = [&](int tick) {
+        if (!col_ok || (g.debug_skip & 4)) return;
+        constexpr int HP = K::H_PITCH / 4;
+        // m handled this tick: [m_lo, m_lo + MS) with m_lo = m_b - (2a-1) + tick*MS; this group's share:
+        const int m_g = m_b - (TAPS - 1) + tick * K::MS + grp * K::MRG;
+        if (m_g + K::MRG <= m_b || m_g >= m_e) return;  // uniform
+        if (g.debug_skip & 64) {  // profiling: the store stream alone (no LDS reads, no arithmetic)
+            for (int mm = 0; mm < K::MRG; mm++)
+                for (int ph = 0; ph < S; ph++) {
+                    const int m = m_g + mm, y = m * S + ph;
+                    if (m >= m_b && m < m_e && y >= y_lo && y < y_hi)
+                        __builtin_amdgcn_raw_buffer_store_b32(col_b + y, orsrc, col_b, (y - g.out_row0) * g.out_pitch, 0);
+                }
+            return;
+        }
+        const uint32_t* hcol = (const uint32_t*)hbuf + col;
+        float win[TAPS][F::VEC];
+        uint32_t raw[TAPS];
+        auto unpack = [&](int slot_i, uint32_t w) {
+            raw[slot_i] = w;
+#pragma unroll
+            for (int e = 0; e < F::VEC; e++) win[slot_i][e] = (float)((w >> (8 * SB * e)) & F::SMASK);
+        };
+        auto ring = [&](int r) { return hcol[((r - hb) & (K::RS - 1)) * HP]; };  // H row r of this column
+        // rows m_g-a+1 .. m_g+a-1 seed the window; rows before hb were never produced: only read for m < m_b,
+        // whose outputs are not stored
+#pragma unroll
+        for (int k = 0; k < TAPS - 1; k++) unpack(k, ring(m_g - A + 1 + k));
+        // every output row of this group's share lies inside the chunk and the stored range: no per-row tests
+        const bool interior = m_g >= m_b && m_g + K::MRG <= m_e && m_g * S >= y_lo && (m_g + K::MRG) * S <= y_hi;
+        const bool no_store = (g.debug_skip & 8) != 0;
+        int soff = (m_g * S - g.out_row0) * g.out_pitch;  // scalar byte offset of the current output row
+        for (int mm = 0; mm < K::MRG; mm += TAPS) {
+#pragma unroll
+            for (int i = 0; i < TAPS; i++) {
+                if (mm + i >= K::MRG) break;
+                const int m = m_g + mm + i;
+                unpack((i + TAPS - 1) % TAPS, ring(m + A));
+#pragma unroll
+                for (int ph = 0; ph < S; ph++) {
+                    const int y = m * S + ph;
+                    uint32_t packed;
+                    bool undecided = false;
+                    if (ph == 0) {
+                        packed = raw[(i + A - 1) % TAPS];
+                        if (EXACT && fc.vlim > 0) {
+#pragma unroll
+                            for (int e = 0; e < F::VEC; e++)
+                                undecided |= (((packed >> (8 * SB * e)) & F::SMASK) - 1u < (unsigned)fc.vlim);
+                        }
+                    } else {
+                        packed = 0;
+                        float accs[F::VEC];
+#pragma unroll
+                        for (int e = 0; e < F::VEC; e++) {
+                            float acc = vbias;
+#pragma unroll
+                            for (int k = 0; k < TAPS; k++) acc = __builtin_fmaf(wv[ph][k], win[(i + k) % TAPS][e], acc);
+                            accs[e] = acc;
+                        }
+                        if (SB == 1 && !EXACT) {
+                            // floor(sum + eps): the sum is biased by eps - 0.5 and the hardware's saturating
+                            // round-to-nearest-even byte convert does the rest (a tie needs fract(sum+eps) == 0,
+                            // an undecided sample, which is within 1 LSB either way)
+#pragma unroll
+                            for (int e = 0; e < 4; e++) packed = __builtin_amdgcn_cvt_pk_u8_f32(accs[e], e, packed);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < F::VEC; e++) {
+                                const float xc = __builtin_amdgcn_fmed3f(accs[e], 0.5f, F::MAXV + 0.5f);
+                                const float fl = __builtin_floorf(xc);
+                                if (EXACT) undecided |= (xc - fl) < fc.near2;
+                                packed |= (unsigned)fl << (8 * SB * e);
+                            }
+                        }
+                    }
+                    if (EXACT) {
+                        if (__any(undecided)) {  // wave-uniform: redo this row's dword in f64 (full_TB.h:71-75)
+                            const int yc = y < 0 ? 0 : (y < g.out_h ? y : g.out_h - 1);
+                            const double* wvd = t.v_w + (size_t)yc * TAPS;
+                            packed = 0;
+#pragma unroll
+                            for (int e = 0; e < F::VEC; e++) {
+                                double sum = 0;
+#pragma unroll
+                                for (int k = 0; k < TAPS; k++) sum += (double)win[(i + k) % TAPS][e] * wvd[k];
+                                packed |= (unsigned)store_convert<T>(sum) << (8 * SB * e);
+                            }
+                        }
+                    }
+                    // uniform; `interior` (the common case) short-circuits the four range tests
+                    if ((interior || (m >= m_b && m < m_e && y >= y_lo && y < y_hi)) && !no_store)
+                        __builtin_amdgcn_raw_buffer_store_b32(packed, orsrc, col_b, soff, 0);
+                    soff += g.out_pitch;
+                }
+            }
+        }
+    };
+
+    // =================================================================== the march
+    issue_loads(0);
+    commit_loads(0);
+    issue_loads(1);
+    commit_loads(1);
+    __syncthreads();
+    hpass(0);
+    __syncthreads();
+    // diagnostic build only (STAMP): where a wave's cycles go, summed over the march, written once at the end
+    unsigned long long tsum[5] = {0, 0, 0, 0, 0};
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long tt = 0;
+        if (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return tt;
+    };
+    for (int tick = 0; tick < ticks; tick++) {
+        const unsigned long long t0 = stamp();
+        issue_loads(tick + 2);              // lands in the buffer HPASS(tick) has finished with
+        const unsigned long long t1 = stamp();
+        if (tick + 1 < ticks) hpass(tick + 1);
+        const unsigned long long t2 = stamp();
+        // commit BEFORE the V pass issues its stores: vmcnt retires in order, so waiting for the prefetch here
+        // only waits for the previous tick's (long finished) stores, never for this tick's
+        commit_loads(tick & 1);
+        const unsigned long long t3 = stamp();
+        vpass(tick);
+        const unsigned long long t4 = stamp();
+        if (!(g.debug_skip & 128)) __syncthreads();  // (profiling bit 128: no barrier -- results are then wrong)
+        const unsigned long long t5 = stamp();
+        if (STAMP) {
+            tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3; tsum[4] += t5 - t4;
+        }
+    }
+    if (STAMP && g.stamps && lane == 0) {
+        unsigned long long* dst = g.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * K::NWAVES + wave) * 6;
+        for (int i = 0; i < 5; i++) dst[i] = tsum[i];
+        dst[5] = (unsigned long long)ticks;
+    }
+}
+
+// the marching kernel moves whole 16-byte chunks: rows, frames and the base must be 16-byte multiples
+inline bool march_supports(const FrameGeom& g) {
+    return g.in_pitch % 16 == 0 && (((uintptr_t)g.in) & 15) == 0 && (g.in_frame_stride & 15) == 0 &&
+           (size_t)g.in_pitch * g.in_rows < (1ull << 31);
+}
+
+// Chunk height: ONE resident round of workgroups.  With more workgroups than the chip holds at once the second
+// round runs part-empty and the launch takes two wave lifetimes; so the (strip, frame) pairs are cut into
+// floor(slots / pairs) chunks each (at least one, a whole number of ticks, at least two ticks).
+inline int march_chunk_rows(int m_rows, int strips, int frames, int ms, int slots) {
+    static const int target_env = getenv("LANCZOS_MARCH_WGS") ? atoi(getenv("LANCZOS_MARCH_WGS")) : 0;
+    const int target = target_env > 0 ? target_env : slots;
+    const int pairs = strips * frames;
+    int chunks = target / pairs;
+    if (chunks < 1) chunks = 1;
+    int rows = (m_rows + chunks - 1) / chunks;
+    rows = (rows + ms - 1) / ms * ms;
+    if (rows < 2 * ms) rows = 2 * ms;
+    return rows;
+}
+
+template <typename T, int C, int S, int A>
+inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g, const TapTables& t,
+                                 const FastConsts& fc, hipStream_t stream) {
+    using K = MarchCfg<T, C, S, A>;
+    using F = typename K::F;
+    const int strips = (g.out_w + F::TWP_OUT - 1) / F::TWP_OUT;
+    const int y_lo = g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows;
+    const int y_hi = g.out_row0 + g.out_rows;
+    if (y_lo >= y_hi) return hipSuccess;
+    const int m_rows = (y_hi - 1) / S - y_lo / S + 1;
+    static int slots[2][64] = {};
+    const bool exact_ = d.mode == LANCZOS_MODE_EXACT;
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    dev_ &= 63;
+    if (slots[exact_][dev_] == 0) {
+        int nb = 0, cus = 0;
+        hipError_t e = exact_ ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march<T, C, S, A, true>, K::NT, K::LDS_BYTES)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march<T, C, S, A, false>, K::NT, K::LDS_BYTES);
+        if (e != hipSuccess || nb < 1) nb = 1;
+        // Measured on MI355X (in-kernel stamps, profiles/): with 6-wave workgroups and ~105 SGPRs the CU admits
+        // one workgroup fewer than the API answers (waves of a workgroup land unevenly on the 4 SIMDs and the
+        // SGPR file caps waves per SIMD; MI355X_MICROARCH.md "Residency").  Sizing the grid for the API's
+        // number leaves a part-empty second round; be conservative when a workgroup is not a multiple of 4 waves.
+        if (nb > 1 && K::NWAVES % 4 != 0) nb -= 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || cus < 1) cus = 256;
+        slots[exact_][dev_] = nb * cus;
+        if (getenv("LANCZOS_VERBOSE"))
+            fprintf(stderr, "lanczos: k_march<%d B,%d ch,x%d,a=%d> %d threads, %d B LDS: %d workgroups/CU x %d CUs\n",
+                    (int)sizeof(T), C, S, A, K::NT, K::LDS_BYTES, nb, cus);
+    }
+    const int chunk_rows = march_chunk_rows(m_rows, strips, g.frames, K::MS, slots[exact_][dev_]);
+    const int chunks = (m_rows + chunk_rows - 1) / chunk_rows;
+    dim3 grid(strips * chunks, g.frames);
+    static const int extra_lds = getenv("LANCZOS_EXTRA_LDS") ? atoi(getenv("LANCZOS_EXTRA_LDS")) : 0;  // occupancy experiments
+    static bool attr_done[2][64] = {};
+    const bool exact = d.mode == LANCZOS_MODE_EXACT;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!attr_done[exact][dev]) {
+        hipError_t e = exact ? hipFuncSetAttribute((const void*)k_march<T, C, S, A, true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + extra_lds)
+                             : hipFuncSetAttribute((const void*)k_march<T, C, S, A, false>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + extra_lds);
+        if (e != hipSuccess) return e;
+        attr_done[exact][dev] = true;
+    }
+    if (exact)
+        hipLaunchKernelGGL((k_march<T, C, S, A, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc, chunk_rows);
+    else if (g.stamps && sizeof(T) == 1 && C == 3 && S == 2 && A == 3) {  // diagnostic build, one configuration
+        using KS = MarchCfg<uint8_t, 3, 2, 3>;
+        hipLaunchKernelGGL((k_march<uint8_t, 3, 2, 3, false, true>), grid, dim3(KS::NT), KS::LDS_BYTES, stream, g, t, fc,
+                           chunk_rows);
+    }
+    else
+        hipLaunchKernelGGL((k_march<T, C, S, A, false>), grid, dim3(K::NT), K::LDS_BYTES + extra_lds, stream, g, t, fc,
+                           chunk_rows);
+    return hipGetLastError();
+}
+
+inline hipError_t march_launch(const lanczos_desc& d, const FrameGeom& g, const TapTables& t, const FastConsts& fc,
+                               hipStream_t stream) {
+#define X(T, C, S, A)                                                                               \
+    if (d.bytes_per_sample == (int)sizeof(T) && d.channels == C && d.scale_n == S && d.a == A)      \
+        return march_launch_t<T, C, S, A>(d, g, t, fc, stream);
+    LZ_FAST_CONFIGS(X)
+#undef X
+    return hipErrorNotSupported;
+}
+
+}  // namespace lz

@@ -1,0 +1,6 @@
+#!/usr/bin/env bash
+# scripts/ablate.sh "<skip values>" [bench args] -- kernel time with phases of the marching kernel switched off
+skips="$1"; shift
+for skip in $skips; do
+  LANCZOS_DEBUG_SKIP=$skip python bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('skip=$skip', d['config']['pattern'], 'kernel_us', d['roofline']['kernel_us'])"
+done

@@ -96,11 +96,16 @@ SHAPES = [
     (514, 131, 3, 2, 1, 3), (320, 99, 3, 3, 1, 3), (700, 50, 3, 2, 1, 3), (130, 300, 3, 2, 1, 3),
     (260, 200, 4, 2, 1, 4), (260, 200, 1, 2, 1, 3), (258, 70, 3, 2, 1, 2), (258, 70, 3, 2, 1, 4),
     (200, 90, 4, 2, 1, 3),
+    # rows that are 16-byte multiples -> the marching kernel (ragged strips, several chunks, tiny heights)
+    (208, 131, 3, 2, 1, 3), (144, 77, 3, 3, 1, 3), (400, 50, 3, 2, 1, 3), (64, 300, 3, 2, 1, 3),
+    (256, 200, 1, 2, 1, 3), (272, 9, 3, 2, 1, 3), (16, 40, 3, 2, 1, 4), (48, 30, 3, 2, 1, 2),
 ]
 FAST_SHAPES = {(200, 120, 3, 2, 1, 3), (160, 90, 3, 3, 1, 3), (128, 96, 3, 2, 1, 2), (96, 64, 4, 2, 1, 4),
                (120, 80, 1, 2, 1, 3), (514, 131, 3, 2, 1, 3), (320, 99, 3, 3, 1, 3), (700, 50, 3, 2, 1, 3),
                (130, 300, 3, 2, 1, 3), (260, 200, 4, 2, 1, 4), (260, 200, 1, 2, 1, 3), (258, 70, 3, 2, 1, 2),
-               (258, 70, 3, 2, 1, 4), (200, 90, 4, 2, 1, 3)}
+               (258, 70, 3, 2, 1, 4), (200, 90, 4, 2, 1, 3), (208, 131, 3, 2, 1, 3), (144, 77, 3, 3, 1, 3),
+               (400, 50, 3, 2, 1, 3), (64, 300, 3, 2, 1, 3), (256, 200, 1, 2, 1, 3), (272, 9, 3, 2, 1, 3),
+               (16, 40, 3, 2, 1, 4), (48, 30, 3, 2, 1, 2)}
 
 
 @pytest.mark.parametrize("mode", [L.MODE_EXACT, L.MODE_LSB1])
