@@ -17,7 +17,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblanczos_hip.so")
+# LANCZOS_LIB: load another build of the same C ABI (A/B experiments); default is the in-tree product build
+LIB_PATH = os.environ.get("LANCZOS_LIB") or os.path.join(_HERE, "liblanczos_hip.so")
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM = range(6)
 MODE_LSB1, MODE_EXACT = 0, 1

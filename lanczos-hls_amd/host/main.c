@@ -1,0 +1,104 @@
+/*
+ * main.c -- the harness: what main.cpp:15-19 + sim_tb (full_TB.h:99-180) do around the resample entry point,
+ * with the reference's compile-time parameters (params.h) turned into command-line arguments.
+ *
+ *   lanczos_upscale <in.(png|ppm|pgm)> <out.(png|ppm|pgm)> [--scale N[/D]] [--a A] [--channels C]
+ *                   [--exact] [--device D] [--repeat K]
+ *
+ * load (interleaved u8 HWC, like stbi_load, full_TB.h:107) -> checks with the reference's messages and
+ * EXIT_FAILURE (full_TB.h:110-123) -> "Scale:%d/%d, WIDTHS %d -> %d" (full_TB.h:124) -> the resample, through
+ * the C ABI (include/lanczos_hip.h; replaces lanczos(stream_in, stream_out), full_TB.h:140) -> write the image
+ * (like stbi_write_png, full_TB.h:172).  Host code is plain C; everything GPU is behind the extern "C" shim.
+ * There is no software fallback: without a GPU the program reports the error and fails.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../../include/lanczos_hip.h"
+#include "image_io.h"
+
+static int ends_with(const char* s, const char* suf) {
+    size_t n = strlen(s), m = strlen(suf);
+    return n >= m && strcmp(s + n - m, suf) == 0;
+}
+
+int main(int argc, char* argv[]) {
+    const char *in_path = NULL, *out_path = NULL;
+    int scale_n = 2, scale_d = 1, a = 3, want_channels = 3, exact = 0, device = 0, repeat = 1;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--scale") && i + 1 < argc) {
+            scale_d = 1;
+            if (sscanf(argv[++i], "%d/%d", &scale_n, &scale_d) < 1) scale_n = 0;
+        } else if (!strcmp(argv[i], "--a") && i + 1 < argc) {
+            a = atoi(argv[++i]);
+        } else if (!strcmp(argv[i], "--channels") && i + 1 < argc) {
+            want_channels = atoi(argv[++i]);
+        } else if (!strcmp(argv[i], "--device") && i + 1 < argc) {
+            device = atoi(argv[++i]);
+        } else if (!strcmp(argv[i], "--repeat") && i + 1 < argc) {
+            repeat = atoi(argv[++i]);
+        } else if (!strcmp(argv[i], "--exact")) {
+            exact = 1;
+        } else if (!in_path) {
+            in_path = argv[i];
+        } else if (!out_path) {
+            out_path = argv[i];
+        }
+    }
+    if (!in_path || !out_path) {
+        fprintf(stderr, "usage: %s <in.png|ppm> <out.png|ppm> [--scale N[/D]] [--a A] [--channels C] [--exact] "
+                        "[--device D] [--repeat K]\n", argv[0]);
+        return EXIT_FAILURE;
+    }
+    printf("Running full TB (%s)\n", lanczos_version());  /* main.cpp:16 */
+
+    int width = 0, height = 0, channels = 0;
+    uint8_t* img = lz_image_load(in_path, &width, &height, &channels, want_channels);
+    if (img == NULL) { /* full_TB.h:110-113 */
+        printf("Image was not loaded successfully.\n");
+        return EXIT_FAILURE;
+    }
+    lanczos_desc d;
+    int rc = lanczos_desc_init(&d, width, height, want_channels, 1, scale_n, scale_d, a);
+    if (rc != LANCZOS_OK) { /* the reference rejects what its compiled-in parameters do not cover (full_TB.h:115-123) */
+        printf("Image has wrong dimensions (%i x %i) or parameters: %s.\n", width, height, lanczos_strerror(rc));
+        return EXIT_FAILURE;
+    }
+    d.mode = exact ? LANCZOS_MODE_EXACT : LANCZOS_MODE_LSB1;
+    printf("Scale:%d/%d, WIDTHS %d -> %d\n", d.scale_n, d.scale_d, d.in_w, d.out_w); /* full_TB.h:124 */
+
+    uint8_t* out = (uint8_t*)malloc(lanczos_out_frame_bytes(&d));
+    lanczos_ctx* ctx = NULL;
+    rc = lanczos_create(&ctx, device);
+    if (rc != LANCZOS_OK || !out) {
+        printf("Cannot use the GPU: %s\n", lanczos_strerror(rc));
+        return EXIT_FAILURE;
+    }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int k = 0; k < repeat && rc == LANCZOS_OK; k++) rc = lanczos_resample_host(ctx, &d, img, out, 1);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (rc != LANCZOS_OK) {
+        printf("lanczos failed: %s (hip error %d)\n", lanczos_strerror(rc), lanczos_last_hip_error(ctx));
+        return EXIT_FAILURE;
+    }
+    const double ms = ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6) / repeat;
+    printf("%dx%d->%dx%d_%d|%d_%d: %.3f ms per frame incl. PCIe copies (%.1f Mpix/s), kernel family %d\n", d.in_w,
+           d.in_h, d.out_w, d.out_h, d.scale_n, d.scale_d, d.a, ms, d.out_w * (double)d.out_h / ms / 1e3,
+           lanczos_last_kernel(ctx));
+
+    int ok = ends_with(out_path, ".png") ? lz_image_write_png(out_path, d.out_w, d.out_h, want_channels, out,
+                                                              d.out_w * want_channels)
+                                         : lz_image_write_pnm(out_path, d.out_w, d.out_h, want_channels, out,
+                                                              d.out_w * want_channels);
+    if (!ok) {
+        printf("Could not write %s\n", out_path);
+        return EXIT_FAILURE;
+    }
+    lanczos_destroy(ctx);
+    lz_image_free(img);
+    free(out);
+    return 0;
+}
