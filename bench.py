@@ -99,7 +99,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--pattern", default="noise")
+    ap.add_argument("--pattern", default="gradient",
+                    help="headline input: gradient (natural-image-like, SURVEY.md 8d), noise (worst case for the "
+                         "integer-phase fix-ups), blocks, dark; the others are reported under other_patterns")
     ap.add_argument("--mode", default="lsb1", choices=["lsb1", "exact"])
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default: 16, c5: 4)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fast"])
@@ -175,6 +177,29 @@ def main():
     achieved = alg_bytes_launch / avg_main_s / 1e9 if avg_main_s > 0 else 0.0
 
     extra = {}
+    # the other synthetic generators of SURVEY.md 8(d), same launch shape, fewer steps -- reported beside the headline
+    others = {}
+    for pat in ("noise", "gradient", "blocks"):
+        if pat == args.pattern:
+            continue
+        x.copy_(make_frames(torch, pat, frames, ih, iw, c, bps, device, seed=4321 + rank))
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ctx.timing_enable(True)
+        ctx.timing_read()
+        n_o = max(3, args.steps // 5)
+        for _ in range(n_o):
+            step()
+        torch.cuda.synchronize()
+        l_o, m_o, _p = ctx.timing_read()
+        ctx.timing_enable(False)
+        k_s = m_o / max(l_o, 1) / 1e3
+        others[pat] = {"kernel_us": round(k_s * 1e6, 2), "roofline_frac": round(alg_bytes_launch / k_s / 1e9 / HBM_PEAK_GBS, 4)}
+    extra["other_patterns"] = others
+    x.copy_(make_frames(torch, args.pattern, frames, ih, iw, c, bps, device, seed=1234 + rank))
+    step()
+    torch.cuda.synchronize()
     if args.exchange and dist is not None:
         # root-inclusive figure: rank 0 scatters every rank's input frames and gathers the outputs (RCCL)
         reps = 3

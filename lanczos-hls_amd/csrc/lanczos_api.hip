@@ -432,13 +432,20 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
 
     if (has_prefix) {
         const int samples_w = d->out_w * d->channels;
-        dim3 grid((samples_w + 255) / 256, frames);
-        if (d->bytes_per_sample == 1)
-            hipLaunchKernelGGL(lz::k_prefix<uint8_t>, grid, dim3(256), 0, stream, g, p->dev, p->prefix.K,
-                               p->prefix.M, p->prefix.M2);
-        else
-            hipLaunchKernelGGL(lz::k_prefix<uint16_t>, grid, dim3(256), 0, stream, g, p->dev, p->prefix.K,
-                               p->prefix.M, p->prefix.M2);
+        dim3 grid((samples_w + 127) / 128, frames);
+#define LZ_PREFIX(T, TAPS)                                                                                       \
+    hipLaunchKernelGGL((lz::k_prefix<T, TAPS>), grid, dim3(128), 0, stream, g, p->dev, p->prefix.K, p->prefix.M, \
+                       p->prefix.M2)
+        if (d->bytes_per_sample == 1) {
+            if (d->a == 2) LZ_PREFIX(uint8_t, 4);
+            else if (d->a == 3) LZ_PREFIX(uint8_t, 6);
+            else LZ_PREFIX(uint8_t, 8);
+        } else {
+            if (d->a == 2) LZ_PREFIX(uint16_t, 4);
+            else if (d->a == 3) LZ_PREFIX(uint16_t, 6);
+            else LZ_PREFIX(uint16_t, 8);
+        }
+#undef LZ_PREFIX
         LZ_HIP(ctx, hipGetLastError());
     }
     if (ev2) LZ_HIP(ctx, hipEventRecord(ev2, stream));

@@ -98,11 +98,11 @@ __global__ __launch_bounds__(kGenTileW) void k_generic(FrameGeom g, TapTables t)
 }
 
 // One thread per (frame, sample column): output rows [0, K) of the in-place vertical pass.
-// pi.M / pi.M2 <= kMaxPrefixRows + kMaxTaps are checked on the host.
-template <typename T>
-__global__ __launch_bounds__(256) void k_prefix(FrameGeom g, TapTables t, int K, int M, int M2) {
+// pi.M / pi.M2 <= kMaxPrefixRows + kMaxTaps are checked on the host.  TAPS is a template parameter so the
+// tap loops unroll and the H-pass loads of a row are all in flight together.
+template <typename T, int TAPS>
+__global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K, int M, int M2) {
     const int C = g.channels;
-    const int taps = 2 * g.a;
     const int samples_w = g.out_w * C;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int frame = blockIdx.y;
@@ -116,23 +116,34 @@ __global__ __launch_bounds__(256) void k_prefix(FrameGeom g, TapTables t, int K,
     {   // horizontal pass of the rows the prefix reads (full_TB.h:55-65)
         const int xx = j / C, c = j - xx * C;
         const int first = t.h_first[xx];
+        int idx[TAPS];
+        double w[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) {
+            int i = first + k;
+            i = i < 0 ? 0 : (i > g.in_w - 1 ? g.in_w - 1 : i);  // weight is 0 there
+            idx[k] = i * C + c;
+            w[k] = t.h_w[(size_t)xx * TAPS + k];
+        }
+#pragma unroll 4
         for (int r = 0; r < M2; r++) {
             const T* row = (const T*)(in_f + (size_t)(r - g.in_row0) * g.in_pitch);
+            T v[TAPS];
+#pragma unroll
+            for (int k = 0; k < TAPS; k++) v[k] = row[idx[k]];
             double sum = 0;
-            for (int k = 0; k < taps; k++) {
-                int i = first + k;
-                i = i < 0 ? 0 : (i > g.in_w - 1 ? g.in_w - 1 : i);
-                sum += (double)row[i * C + c] * t.h_w[(size_t)xx * taps + k];
-            }
+#pragma unroll
+            for (int k = 0; k < TAPS; k++) sum += (double)v[k] * w[k];
             h[r] = store_convert<T>(sum);
         }
     }
     // full_TB.h:69-76, xx descending: a tap at row i > xx sees the value already written there
     for (int xx = M - 1; xx >= 0; xx--) {
         const int first = t.v_first[xx];
-        const double* wv = t.v_w + (size_t)xx * taps;
+        const double* wv = t.v_w + (size_t)xx * TAPS;
         double sum = 0;
-        for (int k = 0; k < taps; k++) {
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) {
             int i = first + k;
             i = i < 0 ? 0 : (i > g.in_h - 1 ? g.in_h - 1 : i);  // weight 0 outside
             const T v = i > xx ? o[i] : h[i];
