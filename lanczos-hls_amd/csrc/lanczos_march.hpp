@@ -25,8 +25,22 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "lanczos_fast.hpp"
+
+// SGPR budget: gfx950 admits min(8, floor(800 / (ceil(sgpr/16)*16 + 16))) waves per SIMD (MI355X_MICROARCH.md,
+// "Residency"); at the compiler's free choice (106) that is 6, and four 6-wave workgroups then only fit when their
+// waves happen to spread evenly over the SIMDs (measured: 3 resident, not the 4 the occupancy API answers).
+// 96 SGPRs -> 7 waves per SIMD: 4 workgroups per CU, +5..9 % (interleaved A/B on one device).
+#ifndef LZ_MARCH_SGPRS
+#define LZ_MARCH_SGPRS 96
+#endif
+#if LZ_MARCH_SGPRS > 0
+#define LZ_MARCH_SGPR_ATTR __attribute__((amdgpu_num_sgpr(LZ_MARCH_SGPRS)))
+#else
+#define LZ_MARCH_SGPR_ATTR
+#endif
 
 namespace lz {
 
@@ -75,7 +89,7 @@ struct MarchCfg {
 };
 
 template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false>
-__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) void k_march(FrameGeom g, TapTables t, FastConsts fc,
+__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc,
                                                                       int chunk_rows) {
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
@@ -369,15 +383,6 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) void k_march(FrameGeom 
         // m handled this tick: [m_lo, m_lo + MS) with m_lo = m_b - (2a-1) + tick*MS; this group's share:
         const int m_g = m_b - (TAPS - 1) + tick * K::MS + grp * K::MRG;
         if (m_g + K::MRG <= m_b || m_g >= m_e) return;  // uniform
-        if (g.debug_skip & 64) {  // profiling: the store stream alone (no LDS reads, no arithmetic)
-            for (int mm = 0; mm < K::MRG; mm++)
-                for (int ph = 0; ph < S; ph++) {
-                    const int m = m_g + mm, y = m * S + ph;
-                    if (m >= m_b && m < m_e && y >= y_lo && y < y_hi)
-                        __builtin_amdgcn_raw_buffer_store_b32(col_b + y, orsrc, col_b, (y - g.out_row0) * g.out_pitch, 0);
-                }
-            return;
-        }
         const uint32_t* hcol = (const uint32_t*)hbuf + col;
         float win[TAPS][F::VEC];
         uint32_t raw[TAPS];
@@ -395,6 +400,10 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) void k_march(FrameGeom 
         const bool interior = m_g >= m_b && m_g + K::MRG <= m_e && m_g * S >= y_lo && (m_g + K::MRG) * S <= y_hi;
         const bool no_store = (g.debug_skip & 8) != 0;
         int soff = (m_g * S - g.out_row0) * g.out_pitch;  // scalar byte offset of the current output row
+        // two instances of the row loop: the interior one (the common case) carries no range tests at all --
+        // the per-row scalar compare/select chains cost more issue slots than the arithmetic they guarded
+        auto rows = [&](auto checked_c) {
+        constexpr bool CHECKED = decltype(checked_c)::value;
         for (int mm = 0; mm < K::MRG; mm += TAPS) {
 #pragma unroll
             for (int i = 0; i < TAPS; i++) {
@@ -453,13 +462,15 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) void k_march(FrameGeom 
                             }
                         }
                     }
-                    // uniform; `interior` (the common case) short-circuits the four range tests
-                    if ((interior || (m >= m_b && m < m_e && y >= y_lo && y < y_hi)) && !no_store)
+                    if ((!CHECKED || (m >= m_b && m < m_e && y >= y_lo && y < y_hi)) && !no_store)  // uniform
                         __builtin_amdgcn_raw_buffer_store_b32(packed, orsrc, col_b, soff, 0);
                     soff += g.out_pitch;
                 }
             }
         }
+        };
+        if (interior) rows(std::integral_constant<bool, false>{});
+        else rows(std::integral_constant<bool, true>{});
     };
 
     // =================================================================== the march
@@ -551,7 +562,7 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g, cons
         // one workgroup fewer than the API answers (waves of a workgroup land unevenly on the 4 SIMDs and the
         // SGPR file caps waves per SIMD; MI355X_MICROARCH.md "Residency").  Sizing the grid for the API's
         // number leaves a part-empty second round; be conservative when a workgroup is not a multiple of 4 waves.
-        if (nb > 1 && K::NWAVES % 4 != 0) nb -= 1;
+        if (LZ_MARCH_SGPRS == 0 && nb > 1 && K::NWAVES % 4 != 0) nb -= 1;  // with the 96-SGPR cap the API's answer holds
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || cus < 1) cus = 256;
         slots[exact_][dev_] = nb * cus;
         if (getenv("LANCZOS_VERBOSE"))
