@@ -227,6 +227,18 @@ def main():
             f0, g0 = f0.view(np.uint16), g0.view(np.uint16)
         cpu = cpu_baseline(f0, cfg, g0)
 
+    # HBM traffic per launch from the PMC counters (collected by scripts/round_profile.sh in separate --pmc
+    # passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; summary committed under profiles/): bench.py itself
+    # cannot run the profiler, so it reports the committed figure for this exact workload or null
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tj = json.load(f)
+        key = f"{args.config}:{frames}"
+        if key in tj:
+            traffic = tj[key]["total_bytes_per_launch"]
+    except Exception:
+        traffic = None
     if rank == 0:
         line = {
             "metric": "output Mpixels/s", "value": round(value, 1), "unit": "Mpix/s",
@@ -238,7 +250,7 @@ def main():
                        "parity_mode": args.mode, "kernel": {1: "generic", 2: "fast"}.get(ctx.last_kernel(), "?"),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel_us": round(avg_main_s * 1e6, 2), "prefix_kernel_us":
                              round(prefix_ms / max(launches, 1) * 1e3, 2),
                          "algorithmic_bytes_per_launch": alg_bytes_launch, "launches_timed": launches},

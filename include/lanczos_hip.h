@@ -97,7 +97,8 @@ int lanczos_destroy(lanczos_ctx* ctx);
 /* Host buffers (what stbi_load returned / what stbi_write_png takes), `frames` frames back to back.
  * Synchronous: copies in, runs, copies out. */
 int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* in, void* out, int frames);
-/* Device buffers, asynchronous on `stream` (a hipStream_t; NULL = the context's own stream).
+/* Device buffers, asynchronous on `stream` (a hipStream_t; NULL = the default stream, so work queued there
+ * by the caller is ordered before the resample).
  * Frame f starts at in + f*in_frame_stride / out + f*out_frame_stride (bytes; 0 = tightly packed). */
 int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in, void* d_out,
                             int frames, size_t in_frame_stride, size_t out_frame_stride, void* stream);

@@ -339,7 +339,9 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
     Plan* p = nullptr;
     rc = get_plan(ctx, d, &p);
     if (rc != LANCZOS_OK) return rc;
-    hipStream_t stream = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    // NULL is the NULL (legacy default) stream -- NOT the context's private stream: a caller whose producers run
+    // on the default stream (torch's default stream is handle 0) must be ordered behind them
+    hipStream_t stream = (hipStream_t)stream_v;
 
     int row0, rows;
     whole_or_strip(d, &row0, &rows);

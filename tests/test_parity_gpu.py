@@ -222,3 +222,39 @@ def test_full_size_properties(ctx):
     small = _oracle(np.full((40, 40, 3), 100, np.uint8), 2, 1, 3)
     assert np.array_equal(out[20:60, 20:60], small[20:60, 20:60])
     assert np.array_equal(out[:40, :40], small[:40, :40])          # top-left corner incl. prefix rows
+
+
+@pytest.mark.parametrize("pattern", ["gradient", "blocks", "dark"])
+def test_full_size_config2_against_oracle(ctx, pattern):
+    """BASELINE config 2 at full size, the non-noise generators, every sample against the CPU checker
+    (the noise generator at full size is covered by the known-answer digests)."""
+    img = P.ALL_U8[pattern](1080, 1920, 3)
+    want = _oracle(img, 2, 1, 3, threads=32)
+    for mode in (L.MODE_LSB1, L.MODE_EXACT):
+        got = ctx.resample(img, 2, 1, 3, mode)
+        _cmp(got, want, mode, f"full-size {pattern}")
+    # the same frames inside a batch of 3 on the device-pointer path the benchmark uses
+    batch = np.stack([img, P.noise(1080, 1920, 3, seed=3), img[::-1].copy()])
+    got = ctx.resample(batch, 2, 1, 3, L.MODE_LSB1)
+    _cmp(got[0], want, L.MODE_LSB1, f"full-size {pattern} in a batch")
+
+
+def test_device_path_is_ordered_behind_the_default_stream(ctx):
+    """lanczos_resample_device(stream=NULL) runs on the default stream: frames produced there by asynchronous
+    device work (a slow generator, as bench.py's does) must be complete before the resample reads them."""
+    import torch
+    dev = torch.device("cuda", 0)
+    d = L.make_desc(960, 540, 3, 2, 1, 3)
+    cfg = O.cfg(960, 540, d.out_w, d.out_h, 3, 3, 2, 1)
+    for rep in range(3):
+        yy = torch.arange(540, device=dev).view(1, 540, 1, 1) // 16
+        xx = torch.arange(960, device=dev).view(1, 1, 960, 1) // 16
+        cc = torch.arange(3, device=dev).view(1, 1, 1, 3)
+        ff = torch.arange(8, device=dev).view(8, 1, 1, 1)
+        x = (((yy + xx + cc + ff + rep) % 5) * 60).to(torch.uint8).contiguous()   # big int64 temporaries: slow
+        y = torch.zeros((8, d.out_h, d.out_w, 3), device=dev, dtype=torch.uint8)
+        ctx.resample_device(d, x.data_ptr(), y.data_ptr(), 8, 0, 0, None)
+        torch.cuda.synchronize()
+        for f in (0, 7):
+            want = O.expected_hwc_u8(cfg, x[f].cpu().numpy(), 8)
+            _cmp(y[f].cpu().numpy(), want, L.MODE_LSB1, f"default-stream ordering rep {rep} frame {f}")
