@@ -7,6 +7,7 @@
 // the in-place prefix rows.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -266,12 +267,69 @@ int lanczos_destroy(lanczos_ctx* ctx) {
         if (hipMemcpy(h.data(), ctx->stamp_buf, kStampBytes, hipMemcpyDeviceToHost) == hipSuccess) {
             double sum[5] = {0, 0, 0, 0, 0}, ticks = 0;
             long n = 0;
-            for (size_t i = 0; i + 5 < h.size(); i += 6)
+            for (size_t i = 0; i + 5 < (size_t)16384 * 8 * 3; i += 6)
                 if (h[i + 5]) {
                     for (int k = 0; k < 5; k++) sum[k] += (double)h[i + k];
                     ticks += (double)h[i + 5];
                     n++;
                 }
+            {   // residency census: per CU, time-averaged and peak number of co-resident workgroups
+                std::map<unsigned long long, std::vector<std::pair<unsigned long long, int>>> ev;
+                const size_t off = (size_t)16384 * 8 * 3;
+                long wgs = 0;
+                unsigned long long tmin = ~0ull, tmax = 0;
+                for (size_t i = off; i + 2 < h.size(); i += 3) {
+                    if (!h[i + 1]) continue;
+                    const unsigned hw = (unsigned)h[i + 2];
+                    const unsigned long long key = ((h[i + 2] >> 32) << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
+                    ev[key].push_back({h[i], +1});
+                    ev[key].push_back({h[i + 1], -1});
+                    if (h[i] < tmin) tmin = h[i];
+                    if (h[i + 1] > tmax) tmax = h[i + 1];
+                    wgs++;
+                }
+                double avg = 0;
+                int peak = 0;
+                for (auto& kv : ev) {
+                    std::sort(kv.second.begin(), kv.second.end());
+                    int cur = 0;
+                    unsigned long long last = tmin, area = 0;
+                    for (auto& e : kv.second) {
+                        area += (unsigned long long)cur * (e.first - last);
+                        last = e.first;
+                        cur += e.second;
+                        if (cur > peak) peak = cur;
+                    }
+                    avg += (double)area / (double)(tmax - tmin ? tmax - tmin : 1);
+                }
+                {   // spread of start times and lifetimes (100 MHz ticks -> us)
+                    std::vector<double> st, life;
+                    for (size_t i = off; i + 2 < h.size(); i += 3)
+                        if (h[i + 1]) {
+                            st.push_back((h[i] - tmin) / 100.0);
+                            life.push_back((h[i + 1] - h[i]) / 100.0);
+                        }
+                    std::sort(st.begin(), st.end());
+                    std::sort(life.begin(), life.end());
+                    if (!st.empty())
+                        fprintf(stderr, "CENSUS start us: p50=%.1f p90=%.1f max=%.1f | lifetime us: min=%.1f p10=%.1f p50=%.1f p90=%.1f max=%.1f\n",
+                                st[st.size() / 2], st[st.size() * 9 / 10], st.back(), life.front(), life[life.size() / 10],
+                                life[life.size() / 2], life[life.size() * 9 / 10], life.back());
+                }
+                if (getenv("LANCZOS_CENSUS_DUMP")) {  // raw records for offline correlation: wg index, start, end, xcc, hw_id
+                    FILE* df = fopen(getenv("LANCZOS_CENSUS_DUMP"), "w");
+                    if (df) {
+                        for (size_t i = off, k = 0; i + 2 < h.size(); i += 3, k++)
+                            if (h[i + 1])
+                                fprintf(df, "%zu %llu %llu %u %u\n", k, h[i] - tmin, h[i + 1] - tmin, (unsigned)(h[i + 2] >> 32),
+                                        (unsigned)h[i + 2]);
+                        fclose(df);
+                    }
+                }
+                if (wgs)
+                    fprintf(stderr, "CENSUS wgs=%ld distinct_cus=%zu span=%.1f us avg_resident_wgs_per_cu=%.2f peak=%d\n", wgs,
+                            ev.size(), (tmax - tmin) / 100.0, avg / ev.size(), peak);
+            }
             if (n)
                 fprintf(stderr, "STAMP waves=%ld ticks/wave=%.1f cycles/tick: issue=%.0f hpass=%.0f commit=%.0f vpass=%.0f barrier=%.0f\n",
                         n, ticks / n, sum[0] / ticks, sum[1] / ticks, sum[2] / ticks, sum[3] / ticks, sum[4] / ticks);

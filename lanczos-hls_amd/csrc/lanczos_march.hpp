@@ -473,6 +473,14 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
         else rows(std::integral_constant<bool, true>{});
     };
 
+    // diagnostic build only: residency census -- when and where (XCC / SE / CU) this workgroup ran
+    unsigned long long census_t0 = 0;
+    unsigned census_hw = 0, census_xcc = 0;
+    if (STAMP) {
+        census_t0 = __builtin_amdgcn_s_memrealtime();
+        census_hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+        census_xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+    }
     // =================================================================== the march
     issue_loads(0);
     commit_loads(0);
@@ -514,6 +522,12 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
         unsigned long long* dst = g.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * K::NWAVES + wave) * 6;
         for (int i = 0; i < 5; i++) dst[i] = tsum[i];
         dst[5] = (unsigned long long)ticks;
+        if (wave == 0) {  // second half of the buffer: one record per workgroup
+            unsigned long long* c = g.stamps + (size_t)16384 * 8 * 3 + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3;
+            c[0] = census_t0;
+            c[1] = __builtin_amdgcn_s_memrealtime();
+            c[2] = ((unsigned long long)census_xcc << 32) | census_hw;
+        }
     }
 }
 
