@@ -38,6 +38,7 @@ struct FastConsts {
     float vbias_rne;                // eps - 0.5: bias under which the RNE byte convert is floor(sum + eps)
     float near2;                    // 2*eps: fract(sum+eps) below this = undecided
     int vlim;                       // integer-phase flip limit (0: the double chain never leaves v0)
+    int skip_last;                  // 1: the last integer-phase tap (x - i = -a, ~1e-33) can never change the sum
     int tight;                      // 1: the only non-negligible negative integer-phase taps sit at +-2 pixels and
                                     //    are < 2^-55, so neighbours <= 2*v0 prove that v0 stays (see fast_prepare)
 };
@@ -518,6 +519,10 @@ inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTap
         }
         fc->tight = ok ? 1 : 0;
     }
+    // Integer-phase chain, last tap (x - i = -a): by then the running sum is v0 +- a few ulp >= 0.5, so its spacing is
+    // >= 2^-54; a term below 2^-55 cannot move it (strictly less than half the spacing: no tie either).  The centre
+    // weight is exactly 1.0 (sinc(0)*sinc(0)), so that product is the sample itself.
+    fc->skip_last = (std::fabs(fc->wi[taps - 1]) * maxv < std::ldexp(1.0, -55) && fc->wi[a - 1] == 1.0) ? 1 : 0;
     if (eps > 0.2) return false;  // f32 cannot even guarantee +-1 LSB
     return true;
 }

@@ -324,8 +324,14 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                     const T* rp = tinT + (erow * K::IN_PITCH + F::LPB) / SB + (fl - A + 1) * C + c;
                     double sum = 0;
                     if (xl - fl * S == 0) {                       // integer phase: the same weights everywhere
+                        if (fc.skip_last) {  // flagged samples have v0 >= 1: the ~1e-33 tap at x-i = -a is inert, L(0) is 1
 #pragma unroll
-                        for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * fc.wi[k];
+                            for (int k = 0; k < TAPS - 1; k++)
+                                sum += k == A - 1 ? (double)rp[k * C] : (double)rp[k * C] * fc.wi[k];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * fc.wi[k];
+                        }
                     } else {
                         const double* w = t.h_w + (size_t)xx * TAPS;
 #pragma unroll
