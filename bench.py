@@ -109,6 +109,10 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU per step (default: 16, c5: 4)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--exchange", action="store_true",
                     help="also time root scatter/gather of the frames over RCCL (N > 1), reported separately")
     args = ap.parse_args()
@@ -125,13 +129,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    red_dev = device if args.backend == "nccl" else torch.device("cpu")  # where the scalar reductions live
 
     cfg = CONFIGS[args.config]
     iw, ih, c, bps, sn, sd, a, desc_txt = cfg
@@ -167,7 +177,7 @@ def main():
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     launches, main_ms, prefix_ms = ctx.timing_read()
@@ -216,7 +226,7 @@ def main():
             dist.gather(y, yout, dst=0)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         extra["root_scatter_gather"] = {"value": round(world * out_pix_step * reps / float(t.item()) / 1e6, 1),
                                         "unit": "Mpix/s", "note": "rank 0 scatters inputs / gathers outputs over RCCL"}
