@@ -67,6 +67,13 @@ def build(verbose=False):
 def _lib():
     global _LIB
     if _LIB is None:
+        if not os.path.exists(LIB_PATH) and not os.environ.get("LANCZOS_LIB"):
+            try:  # a fresh checkout: compile the product (hipcc, ~40 s).  This is a build step, not a fallback.
+                build()
+            except Exception as e:
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing and `make -C lanczos-hls_amd` failed ({e}); "
+                    "there is no CPU fallback") from e
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `make -C lanczos-hls_amd` "
