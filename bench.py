@@ -113,6 +113,8 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--host-path", action="store_true",
+                    help="also time lanczos_resample_host (PCIe copies included, page-locked buffers), reported separately")
     ap.add_argument("--exchange", action="store_true",
                     help="also time root scatter/gather of the frames over RCCL (N > 1), reported separately")
     args = ap.parse_args()
@@ -231,6 +233,24 @@ def main():
         extra["root_scatter_gather"] = {"value": round(world * out_pix_step * reps / float(t.item()) / 1e6, 1),
                                         "unit": "Mpix/s", "note": "rank 0 scatters inputs / gathers outputs over RCCL"}
 
+    if args.host_path and rank == 0:
+        # PCIe-inclusive rate: host buffers in, host buffers out, through the pipelined lanczos_resample_host.
+        # Never `value` (inputs must be resident in HBM for that); DESIGN.md quotes this figure.
+        pin_in = L.PinnedArray((frames, ih, iw, c), x.cpu().numpy().dtype if bps == 1 else "uint16")
+        pin_out = L.PinnedArray((frames, d.out_h, d.out_w, c), pin_in.dtype)
+        src = x.cpu().numpy()
+        pin_in.array[...] = src if bps == 1 else src.view("uint16")
+        ctx.resample(pin_in.array, sn, sd, a, mode, out=pin_out.array)  # warm-up
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            ctx.resample(pin_in.array, sn, sd, a, mode, out=pin_out.array)
+        dt = (time.perf_counter() - t0) / reps
+        extra["host_path_pinned"] = {"value": round(frames * d.out_w * d.out_h / dt / 1e6, 1), "unit": "Mpix/s",
+                                     "ms_per_batch": round(dt * 1e3, 3), "frames": frames,
+                                     "note": "H2D + resample + D2H, three streams, page-locked buffers"}
+        pin_in.close()
+        pin_out.close()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import numpy as np

@@ -93,9 +93,14 @@ int lanczos_taps_host(const lanczos_desc* d, int axis, int32_t* first, double* w
 int lanczos_create(lanczos_ctx** ctx, int device);
 int lanczos_destroy(lanczos_ctx* ctx);
 
+/* Page-locked host memory for lanczos_resample_host callers that want the copies overlapped. */
+int lanczos_host_alloc(void** p, size_t bytes);
+int lanczos_host_free(void* p);
+
 /* ---- the resample ---- */
 /* Host buffers (what stbi_load returned / what stbi_write_png takes), `frames` frames back to back.
- * Synchronous: copies in, runs, copies out. */
+ * Synchronous for the caller; inside, groups of frames are pipelined over copy-in / resample / copy-out
+ * streams, which overlaps the PCIe copies when the buffers are page-locked (lanczos_host_alloc). */
 int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* in, void* out, int frames);
 /* Device buffers, asynchronous on `stream` (a hipStream_t; NULL = the default stream, so work queued there
  * by the caller is ordered before the resample).

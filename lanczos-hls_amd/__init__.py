@@ -28,7 +28,8 @@ KERNEL_NONE, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2
 ABI_SYMBOLS = [
     "lanczos_desc_init", "lanczos_validate", "lanczos_inplace_rows", "lanczos_strip_input_rows",
     "lanczos_in_frame_bytes", "lanczos_out_frame_bytes", "lanczos_kernel", "lanczos_kernel_idx",
-    "lanczos_taps_host", "lanczos_create", "lanczos_destroy", "lanczos_resample_host",
+    "lanczos_taps_host", "lanczos_create", "lanczos_destroy", "lanczos_host_alloc", "lanczos_host_free",
+    "lanczos_resample_host",
     "lanczos_resample_device", "lanczos_u8", "lanczos_timing_enable", "lanczos_timing_read",
     "lanczos_last_kernel", "lanczos_last_hip_error", "lanczos_force_kernel", "lanczos_strerror",
     "lanczos_version",
@@ -97,6 +98,8 @@ def _lib():
         L.lanczos_taps_host.argtypes = [PD, c_int, c_void_p, c_void_p]
         L.lanczos_create.argtypes = [ctypes.POINTER(c_void_p), c_int]
         L.lanczos_destroy.argtypes = [c_void_p]
+        L.lanczos_host_alloc.argtypes = [ctypes.POINTER(c_void_p), c_size_t]
+        L.lanczos_host_free.argtypes = [c_void_p]
         L.lanczos_resample_host.argtypes = [c_void_p, PD, c_void_p, c_void_p, c_int]
         L.lanczos_resample_device.argtypes = [c_void_p, PD, c_void_p, c_void_p, c_int, c_size_t, c_size_t,
                                               c_void_p]
@@ -160,6 +163,32 @@ def taps_host(desc, axis):
     return first, w
 
 
+class PinnedArray:
+    """A numpy array over page-locked host memory (lanczos_host_alloc) -- lets lanczos_resample_host overlap
+    its PCIe copies.  Keep the object alive while the array is in use."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.shape = tuple(int(v) for v in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._p = ctypes.c_void_p()
+        _check(_lib().lanczos_host_alloc(ctypes.byref(self._p), self.nbytes), "lanczos_host_alloc")
+        buf = (ctypes.c_uint8 * self.nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            _lib().lanczos_host_free(self._p)
+            self._p = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One lanczos_ctx: a device, a stream, resident tap tables.  Not shared between threads."""
 
@@ -179,8 +208,9 @@ class Context:
             pass
 
     # -- host buffers: the drop-in for lanczos(stream_in, stream_out) at full_TB.h:140
-    def resample(self, img, scale_n, scale_d, a, mode=MODE_LSB1):
-        """img: [H][W][C] (or [F][H][W][C]) uint8/uint16, stb interleaved layout -> scaled image(s)."""
+    def resample(self, img, scale_n, scale_d, a, mode=MODE_LSB1, out=None):
+        """img: [H][W][C] (or [F][H][W][C]) uint8/uint16, stb interleaved layout -> scaled image(s).
+        `out`: optional preallocated result (e.g. a PinnedArray's .array)."""
         img = np.ascontiguousarray(img)
         batched = img.ndim == 4
         x = img if batched else img[None]
@@ -188,7 +218,12 @@ class Context:
             raise LanczosError(ERR_BAD_ARG, "resample: expected [H][W][C] uint8/uint16")
         f, h, w, c = x.shape
         d = make_desc(w, h, c, scale_n, scale_d, a, x.dtype.itemsize, mode)
-        out = np.empty((f, d.out_h, d.out_w, c), dtype=x.dtype)
+        if out is None:
+            out = np.empty((f, d.out_h, d.out_w, c), dtype=x.dtype)
+        else:
+            if out.dtype != x.dtype or out.size != f * d.out_h * d.out_w * c or not out.flags["C_CONTIGUOUS"]:
+                raise LanczosError(ERR_BAD_ARG, "resample: `out` has the wrong size/dtype/layout")
+            out = out.reshape((f, d.out_h, d.out_w, c))
         _check(_lib().lanczos_resample_host(self._h, ctypes.byref(d), x.ctypes.data, out.ctypes.data, f),
                "lanczos_resample_host")
         return out if batched else out[0]

@@ -60,6 +60,8 @@ struct lanczos_ctx {
     int launches = 0;
     double main_ms = 0, prefix_ms = 0;
     void* stamp_buf = nullptr;
+    hipStream_t copy_in = nullptr, copy_out = nullptr;  // lanczos_resample_host pipeline
+    std::vector<hipEvent_t> pipe_ev;
 };
 static constexpr size_t kStampBytes = 16384 * 8 * 6 * 8;
 
@@ -337,6 +339,9 @@ int lanczos_destroy(lanczos_ctx* ctx) {
         (void)hipFree(ctx->stamp_buf);
     }
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
+    if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
+    if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -512,11 +517,26 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
     return LANCZOS_OK;
 }
 
+int lanczos_host_alloc(void** p, size_t bytes) {
+    if (!p || bytes == 0) return LANCZOS_ERR_BAD_ARG;
+    *p = nullptr;
+    return hipHostMalloc(p, bytes, hipHostMallocDefault) == hipSuccess ? LANCZOS_OK : LANCZOS_ERR_NOMEM;
+}
+
+int lanczos_host_free(void* p) {
+    if (!p) return LANCZOS_OK;
+    return hipHostFree(p) == hipSuccess ? LANCZOS_OK : LANCZOS_ERR_HIP;
+}
+
+// Host buffers in, host buffers out.  Frames are pushed through in groups on three streams (copy-in, resample,
+// copy-out) chained by events, so with page-locked buffers (lanczos_host_alloc, or the caller's own registered
+// memory) the PCIe copies of neighbouring groups overlap each other and the kernels; with pageable memory the
+// runtime stages the copies and the calls degrade to the serial order -- same results either way.
 int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* in, void* out, int frames) {
     if (!ctx || !in || !out || frames <= 0) return LANCZOS_ERR_BAD_ARG;
     int rc = lz::validate(d);
     if (rc != LANCZOS_OK) return rc;
-    size_t in_bytes, out_bytes;
+    size_t in_frame, out_frame;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
         LZ_HIP(ctx, hipSetDevice(ctx->device));
@@ -526,8 +546,9 @@ int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* i
         int row0, rows, in_row0, in_rows;
         whole_or_strip(d, &row0, &rows);
         strip_input_rows(p->V, d->a, d->in_h, row0, rows, p->prefix, &in_row0, &in_rows);
-        in_bytes = (size_t)d->in_w * d->channels * d->bytes_per_sample * in_rows * frames;
-        out_bytes = (size_t)d->out_w * d->channels * d->bytes_per_sample * rows * frames;
+        in_frame = (size_t)d->in_w * d->channels * d->bytes_per_sample * in_rows;
+        out_frame = (size_t)d->out_w * d->channels * d->bytes_per_sample * rows;
+        const size_t in_bytes = in_frame * frames, out_bytes = out_frame * frames;
         if (ctx->stage_in_bytes < in_bytes) {
             if (ctx->stage_in) (void)hipFree(ctx->stage_in);
             ctx->stage_in = nullptr;
@@ -542,13 +563,45 @@ int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* i
             LZ_HIP(ctx, hipMalloc(&ctx->stage_out, out_bytes));
             ctx->stage_out_bytes = out_bytes;
         }
-        LZ_HIP(ctx, hipMemcpyAsync(ctx->stage_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (!ctx->copy_in) LZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
+        if (!ctx->copy_out) LZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
     }
-    rc = lanczos_resample_device(ctx, d, ctx->stage_in, ctx->stage_out, frames, 0, 0, ctx->stream);
-    if (rc != LANCZOS_OK) return rc;
+    // groups of at most 4 frames, at most 64 groups in flight per call
+    int group = frames >= 8 ? 4 : (frames >= 2 ? (frames + 1) / 2 : 1);
+    if ((frames + group - 1) / group > 64) group = (frames + 63) / 64;
+    const int ngroups = (frames + group - 1) / group;
     {
         std::lock_guard<std::mutex> lock(ctx->mu);
-        LZ_HIP(ctx, hipMemcpyAsync(out, ctx->stage_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        while ((int)ctx->pipe_ev.size() < 2 * ngroups) {
+            hipEvent_t e;
+            LZ_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->pipe_ev.push_back(e);
+        }
+    }
+    for (int gi = 0; gi < ngroups; gi++) {
+        const int f0 = gi * group, nf = (f0 + group <= frames) ? group : frames - f0;
+        const uint8_t* hin = (const uint8_t*)in + (size_t)f0 * in_frame;
+        uint8_t* din = (uint8_t*)ctx->stage_in + (size_t)f0 * in_frame;
+        uint8_t* dout = (uint8_t*)ctx->stage_out + (size_t)f0 * out_frame;
+        uint8_t* hout = (uint8_t*)out + (size_t)f0 * out_frame;
+        {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            LZ_HIP(ctx, hipMemcpyAsync(din, hin, in_frame * nf, hipMemcpyHostToDevice, ctx->copy_in));
+            LZ_HIP(ctx, hipEventRecord(ctx->pipe_ev[2 * gi], ctx->copy_in));
+            LZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_ev[2 * gi], 0));
+        }
+        rc = lanczos_resample_device(ctx, d, din, dout, nf, 0, 0, ctx->stream);
+        if (rc != LANCZOS_OK) return rc;
+        {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            LZ_HIP(ctx, hipEventRecord(ctx->pipe_ev[2 * gi + 1], ctx->stream));
+            LZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_out, ctx->pipe_ev[2 * gi + 1], 0));
+            LZ_HIP(ctx, hipMemcpyAsync(hout, dout, out_frame * nf, hipMemcpyDeviceToHost, ctx->copy_out));
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        LZ_HIP(ctx, hipStreamSynchronize(ctx->copy_out));
         LZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return LANCZOS_OK;

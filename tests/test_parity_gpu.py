@@ -258,3 +258,20 @@ def test_device_path_is_ordered_behind_the_default_stream(ctx):
         for f in (0, 7):
             want = O.expected_hwc_u8(cfg, x[f].cpu().numpy(), 8)
             _cmp(y[f].cpu().numpy(), want, L.MODE_LSB1, f"default-stream ordering rep {rep} frame {f}")
+
+
+def test_host_path_pipeline_with_pinned_buffers(ctx):
+    """lanczos_resample_host pushes groups of frames through copy-in / resample / copy-out streams; with
+    page-locked buffers (lanczos_host_alloc) the copies overlap.  Results must not depend on the grouping."""
+    n = 9   # -> groups of 4, 4, 1
+    pin_in = L.PinnedArray((n, 120, 208, 3), np.uint8)
+    pin_out = L.PinnedArray((n, 240, 416, 3), np.uint8)
+    for i in range(n):
+        pin_in.array[i] = P.noise(120, 208, 3, seed=300 + i)
+    got = ctx.resample(pin_in.array, 2, 1, 3, L.MODE_EXACT, out=pin_out.array)
+    for i in range(n):
+        assert np.array_equal(got[i], _oracle(pin_in.array[i], 2, 1, 3)), i
+    pageable = ctx.resample(np.array(pin_in.array), 2, 1, 3, L.MODE_EXACT)
+    assert np.array_equal(pageable, got)
+    pin_in.close()
+    pin_out.close()
