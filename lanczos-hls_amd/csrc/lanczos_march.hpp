@@ -150,20 +150,25 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
             *(u32x4*)(smem + buf * K::TIN_BYTES + (tid + it * K::NT) * 16) = pre[it];
     };
 
-    // ---- constants kept in SGPRs for the whole march
+    // ---- phase weights, pinned in VGPRs for the whole march.  Measured on gfx950 (scripts/probes/probe_valu3.hip): a VALU
+    // instruction with an SGPR source issues at ~1.9 ns per wave, the same instruction with VGPR / inline-constant
+    // sources at ~1.1 ns -- so the (S-1)*2a weights cost registers, not the constant bus.
     float wv[S][TAPS];
 #pragma unroll
     for (int ph = 1; ph < S; ph++)
 #pragma unroll
         for (int k = 0; k < TAPS; k++) {
             wv[ph][k] = fc.wf[ph][k];
-            asm volatile("" : "+s"(wv[ph][k]));
+            asm volatile("" : "+v"(wv[ph][k]));
         }
     constexpr uint32_t HALF = SB == 1 ? 0x80u : 0x8000u;
+    const uint32_t addc1 = (uint32_t)fc.vlim < HALF - 1 ? HALF - 1 - (uint32_t)fc.vlim : 0;
+    // the chain bias and the SWAR masks live in VGPRs for the same reason (a literal is a constant-bus read too)
+    float hbias = fc.bias;
     constexpr uint32_t LOW = SB == 1 ? 0x7f7f7f7fu : 0x7fff7fffu;
     constexpr uint32_t TOP = SB == 1 ? 0x80808080u : 0x80008000u;
-    const uint32_t addc1 = (uint32_t)fc.vlim < HALF - 1 ? HALF - 1 - (uint32_t)fc.vlim : 0;
     const uint32_t addc = SB == 1 ? addc1 * 0x01010101u : addc1 * 0x00010001u;
+    asm volatile("" : "+v"(hbias));
 
     // =================================================================== HPASS + FIXUP of one tick
     auto hpass = [&](int tick) {
@@ -191,7 +196,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                 if (ph == 0) continue;
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    float acc = fc.bias;
+                    float acc = hbias;
 #pragma unroll
                     for (int k = 0; k < TAPS; k++) acc = __builtin_fmaf(wv[ph][k], f[(p + k) * C + c], acc);
                     // below 1 / above max the store clamps: nothing to decide there
@@ -275,7 +280,10 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                 uint32_t loose[F::UNIT_IN_DW], any = 0;
 #pragma unroll
                 for (int i = 0; i < F::UNIT_IN_DW; i++) {
-                    loose[i] = swar_in_1_vlim<SB>(wd[OWN_DW0 + i], addc);  // 1 <= v0 <= vlim
+                    {   // 1 <= v0 <= vlim, per byte/halfword lane (swar_in_1_vlim with the masks in registers)
+                        const uint32_t x = wd[OWN_DW0 + i], t7 = x & LOW;
+                        loose[i] = ((t7 + LOW) | x) & ~((t7 + addc) | x) & TOP;
+                    }
                     any |= loose[i];
                 }
                 if (!fc.tight) {
@@ -381,7 +389,8 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     const bool col_ok = grp < K::NGRP && col_b + 4 <= (unsigned)(g.out_w * C * SB);
     const __amdgpu_buffer_rsrc_t orsrc =
         __builtin_amdgcn_make_buffer_rsrc(out_f, 0, (unsigned)(g.out_rows * g.out_pitch), 0x00020000);
-    const float vbias = (SB == 1 && !EXACT) ? fc.vbias_rne : fc.bias;
+    float vbias = (SB == 1 && !EXACT) ? fc.vbias_rne : fc.bias;
+    asm volatile("" : "+v"(vbias));
 
     auto vpass = [&](int tick) {
         if (!col_ok || (g.debug_skip & 4)) return;
