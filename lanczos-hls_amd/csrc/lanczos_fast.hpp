@@ -23,6 +23,7 @@
 // Output rows < skip_rows (the in-place prefix, full_TB.h:67-77) are left to k_prefix.
 #pragma once
 #include <cmath>
+#include <cstring>
 
 #include "lanczos_kernels_common.hpp"
 #include "lanczos_taps.hpp"
@@ -34,6 +35,9 @@ constexpr int kFastMaxS = 4;
 struct FastConsts {
     float wf[kFastMaxS][kMaxTaps];  // [phase][tap] f32 weights (phase 0 is the integer phase: unused)
     double wi[kMaxTaps];            // integer-phase double weights L(a-1-k): {..,-1.6e-17,3.2e-17,1,3.2e-17,..}
+    double wd[kFastMaxS][kMaxTaps]; // [phase][tap] double weights of an interior output index
+    int phase_exact_h;              // 1: EVERY horizontal output index carries exactly wd[index % S] on its in-range taps
+                                    //    (x = xx/S is exact in double, e.g. S = 2), so the exact chain needs no table
     float bias;                     // eps: f32-chain error bound, added to every sum
     float vbias_rne;                // eps - 0.5: bias under which the RNE byte convert is floor(sum + eps)
     float near2;                    // 2*eps: fract(sum+eps) below this = undecided
@@ -216,7 +220,10 @@ __global__ __launch_bounds__((FastCfg<T, C, S, A>::NT)) void k_fast(FrameGeom g,
                 for (int c = 0; c < C; c++) {
                     float acc = fc.bias;
 #pragma unroll
-                    for (int k = 0; k < TAPS; k++) acc = __builtin_fmaf(fc.wf[ph][k], f[(p + k) * C + c], acc);
+                    for (int j = 0; j < TAPS; j++) {
+                        const int k = f32_tap_order(j, TAPS);  // outside in: the bound of fc.bias assumes this order
+                        acc = __builtin_fmaf(fc.wf[ph][k], f[(p + k) * C + c], acc);
+                    }
                     // below 1 / above max the store clamps: nothing to decide there
                     const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, K::MAXV + 0.5f);
                     const float fl = __builtin_floorf(xc);
@@ -429,8 +436,10 @@ __global__ __launch_bounds__((FastCfg<T, C, S, A>::NT)) void k_fast(FrameGeom g,
                             for (int e = 0; e < K::VEC; e++) {
                                 float acc = vbias;
 #pragma unroll
-                                for (int k = 0; k < TAPS; k++)
+                                for (int j = 0; j < TAPS; j++) {
+                                    const int k = f32_tap_order(j, TAPS);
                                     acc = __builtin_fmaf(wv[ph][k], win[(i + k) % TAPS][e], acc);
+                                }
                                 accs[e] = acc;
                             }
                             if (SB == 1 && !EXACT) {
@@ -489,6 +498,7 @@ inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTap
         for (int k = 0; k < taps; k++) fc->wf[ph][k] = (float)w[k];
         if (ph == 0)
             for (int k = 0; k < taps; k++) fc->wi[k] = w[k];
+        for (int k = 0; k < kMaxTaps; k++) fc->wd[ph][k] = k < taps ? w[k] : 0.0;
         if (ph != 0) {
             const double e = f32_chain_error_bound(w, taps, maxv);
             if (e > eps) eps = e;
@@ -524,6 +534,20 @@ inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTap
     // weight is exactly 1.0 (sinc(0)*sinc(0)), so that product is the sample itself.
     fc->skip_last = (std::fabs(fc->wi[taps - 1]) * maxv < std::ldexp(1.0, -55) && fc->wi[a - 1] == 1.0) ? 1 : 0;
     if (eps > 0.2) return false;  // f32 cannot even guarantee +-1 LSB
+    {   // are the table rows of the horizontal axis the phase weights, bit for bit?  (out-of-range taps are 0 in the
+        // table and meet zero samples in the kernels: a +-0.0 term either way)
+        bool same = true;
+        for (int xx = 0; xx < H.out_n && same; xx++)
+            for (int k = 0; k < taps; k++) {
+                const int i = H.first[xx] + k;
+                if (i < 0 || i >= H.in_n) continue;
+                if (std::memcmp(&H.w[(size_t)xx * taps + k], &fc->wd[xx % S][k], sizeof(double)) != 0) {
+                    same = false;
+                    break;
+                }
+            }
+        fc->phase_exact_h = same ? 1 : 0;
+    }
     return true;
 }
 

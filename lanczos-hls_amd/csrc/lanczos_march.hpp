@@ -75,7 +75,8 @@ struct MarchCfg {
     static constexpr int TIN_BYTES = LOAD_IT * NT * 16;              // >= MS*IN_PITCH: every lane commits a chunk
     // worklist entries per wave: one round of candidates.  (A list for all VEC rounds with a single dense pass
     // measured 13 % SLOWER, interleaved A/B on one device: the extra 7 KiB of LDS costs residency.)
-    static constexpr int WLW = 64 * F::UNIT_IN_DW;
+    static constexpr int WL_ROUND = 64 * F::UNIT_IN_DW;               // most entries one round can add
+    static constexpr int WLW = WL_ROUND + 128;                        // sparse flags: all rounds share ONE dense pass
     static constexpr int LDS_TIN = 2 * TIN_BYTES;                    // double buffered
     static constexpr int LDS_HBUF = RS * H_PITCH;
     static constexpr int LDS_WL = NWAVES * WLW * 2;
@@ -248,7 +249,10 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                     if (ph == 0) continue;
                     float acc = hbias;
 #pragma unroll
-                    for (int k = 0; k < TAPS; k++) acc = __builtin_fmaf(wv[ph][k], fch[p + k], acc);
+                    for (int j = 0; j < TAPS; j++) {
+                        const int k = f32_tap_order(j, TAPS);  // outside in: the bound of fc.bias assumes this order
+                        acc = __builtin_fmaf(wv[ph][k], fch[p + k], acc);
+                    }
                     // below 1 / above max the store clamps: nothing to decide there
                     const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, F::MAXV + 0.5f);
                     const float fl = __builtin_floorf(xc);
@@ -306,9 +310,9 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                 }
             }
         }
-        if (g.debug_skip & 32) {
-            im = 0;
-            near = false;
+        if (g.debug_skip & (32 | 256 | 512)) {  // profiling bits: 32 no flags at all, 256 no near flags, 512 no integer flags
+            if (g.debug_skip & (32 | 512)) im = 0;
+            if (g.debug_skip & (32 | 256)) near = false;
         }
 
         // ---- wave-private compaction of the undecided samples, then the exact chain, densely
@@ -336,6 +340,17 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
 #pragma unroll
                             for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * fc.wi[k];
                         }
+                    } else if (fc.phase_exact_h) {
+                        // every index of a phase has the same weights: kernel arguments, no table gather on the
+                        // critical path (a wave that finds a near-integer sum holds its workgroup's barrier)
+                        const int ph = xl - fl * S;
+#pragma unroll
+                        for (int k = 0; k < TAPS; k++) {
+                            double w = fc.wd[1][k];
+#pragma unroll
+                            for (int q = 2; q < S; q++) w = ph == q ? fc.wd[q][k] : w;
+                            sum += (double)rp[k * C] * w;
+                        }
                     } else {
                         const double* w = t.h_w + (size_t)xx * TAPS;
 #pragma unroll
@@ -358,13 +373,15 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
             // integer-phase candidates: one round per byte/halfword lane e of the own dwords (runtime loop so the
             // exact chain in flush() is not replicated per sample position); a round adds <= 64*UNIT_IN_DW entries
 #pragma unroll 1
-            for (int e = 0; e < F::VEC; e++) {
+            for (int e = 0; e <= F::VEC; e++) {  // the extra trip only drains the list (one flush() site)
+                if (e < F::VEC) {
 #pragma unroll
-                for (int i = 0; i < F::UNIT_IN_DW; i++) {
-                    const int si = i * F::VEC + e, p = si / C, c = si - p * C;  // own input sample -> its integer phase
-                    append((im >> (8 * SB * e + i)) & 1, (p * S) * C + c);
+                    for (int i = 0; i < F::UNIT_IN_DW; i++) {
+                        const int si = i * F::VEC + e, p = si / C, c = si - p * C;  // own input sample -> its integer phase
+                        append((im >> (8 * SB * e + i)) & 1, (p * S) * C + c);
+                    }
                 }
-                if (cnt > 0) flush();
+                if (cnt > K::WLW - K::WL_ROUND || (e == F::VEC && cnt > 0)) flush();
             }
             if (__any(near)) {  // rare: every non-integer-phase sample of the flagged units
 #pragma unroll 1
@@ -440,7 +457,10 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                         for (int e = 0; e < F::VEC; e++) {
                             float acc = vbias;
 #pragma unroll
-                            for (int k = 0; k < TAPS; k++) acc = __builtin_fmaf(wv[ph][k], win[(i + k) % TAPS][e], acc);
+                            for (int j = 0; j < TAPS; j++) {
+                                const int k = f32_tap_order(j, TAPS);
+                                acc = __builtin_fmaf(wv[ph][k], win[(i + k) % TAPS][e], acc);
+                            }
                             accs[e] = acc;
                         }
                         if (SB == 1 && !EXACT) {

@@ -82,12 +82,19 @@ int validate(const lanczos_desc* d) {
 }
 
 double f32_chain_error_bound(const double* w, int ntaps, double maxv) {
-    double sabs = 0;
-    for (int k = 0; k < ntaps; k++) sabs += std::fabs(w[k]);
-    const double bmax = maxv * sabs + 1.0;  // any partial sum, bias included
+    // acc_0 = bias; acc_j = fl(wf[k_j] * v[k_j] + acc_{j-1}) with ONE rounding per fmaf:
+    //   |acc_j - (wf*v + acc_{j-1})| <= u * |wf*v + acc_{j-1}| <= u * P_j,   P_j = |bias| + maxv * sum_{i<=j} |wf[k_i]| (+ earlier errors)
+    // plus the weights themselves: |wf - w| * maxv per tap, taken exactly.
     const double u = std::ldexp(1.0, -24);  // f32 unit roundoff
-    // weight rounding (sabs*maxv*u) + one rounding per fmaf (ntaps * bmax * u), 5 % slack
-    return 1.05 * (ntaps + 1) * bmax * u;
+    double P = 0.5 + 1e-3, err = 0, wq = 0;
+    for (int j = 0; j < ntaps; j++) {
+        const int k = f32_tap_order(j, ntaps);
+        const double wf = (double)(float)w[k];
+        P += maxv * std::fabs(wf);
+        err += u * (P + err);
+        wq += std::fabs(wf - w[k]) * maxv;
+    }
+    return 1.02 * (err + wq);  // 2 % slack
 }
 
 int integer_phase_flip_limit(const double* wi, int a, int maxv) {

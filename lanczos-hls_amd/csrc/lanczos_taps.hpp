@@ -42,6 +42,11 @@ int gcd(int a, int b);  // stb.cpp:9-12 (the reference reduces SCALE_N/SCALE_D w
 
 // f32 error bound of an n-tap fmaf chain against the exact sum, for samples <= maxv and the given
 // weights: used as the half-width of the "too close to an integer to trust f32" window.
+// Order in which the f32 chains of the specialised kernels add their taps: from the outside in
+// (0, n-1, 1, n-2, ...), i.e. roughly ascending |weight|, so that the partial sums -- and with them the rounding
+// error of every fmaf -- stay small until the last two steps.
+constexpr int f32_tap_order(int step, int ntaps) { return (step & 1) ? ntaps - 1 - step / 2 : step / 2; }
+// Rigorous bound on |f32 chain - real sum| for samples in [0,maxv], taps added in f32_tap_order, start value |bias| <= 0.5
 double f32_chain_error_bound(const double* w, int ntaps, double maxv);
 
 // Largest centre sample v0 for which the integer-phase double chain can still end below v0
