@@ -42,6 +42,13 @@
 #define LZ_MARCH_SGPR_ATTR
 #endif
 
+// Cache policy of the output stores: non-temporal + system scope (nt sc1).  The output is written once and never read
+// by the kernel; letting it allocate in L2 evicts the input rows that neighbouring workgroups re-read.  Measured
+// (interleaved A/B, config 2): default 122 us, nt 112 us, nt+sc0 112 us, nt+sc1 110 us; nt on the input LOADS: 125 us.
+#ifndef LZ_STORE_AUX
+#define LZ_STORE_AUX 18
+#endif
+
 namespace lz {
 
 template <typename T, int C, int S, int A>
@@ -494,7 +501,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                         }
                     }
                     if ((!CHECKED || (m >= m_b && m < m_e && y >= y_lo && y < y_hi)) && !no_store)  // uniform
-                        __builtin_amdgcn_raw_buffer_store_b32(packed, orsrc, col_b, soff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(packed, orsrc, col_b, soff, LZ_STORE_AUX);
                     soff += g.out_pitch;
                 }
             }
