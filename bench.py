@@ -115,6 +115,8 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--planar-path", action="store_true",
+                    help="also time planar-in / planar-out frames (device layout conversion either side), reported separately")
     ap.add_argument("--host-path", action="store_true",
                     help="also time lanczos_resample_host (PCIe copies included, page-locked buffers), reported separately")
     ap.add_argument("--exchange", action="store_true",
@@ -242,6 +244,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         extra["root_scatter_gather"] = {"value": round(world * out_pix_step * reps / float(t.item()) / 1e6, 1),
                                         "unit": "Mpix/s", "note": "rank 0 scatters inputs / gathers outputs over RCCL"}
+
+    if args.planar_path and rank == 0:
+        # Callers that hold the reference's planar img[C][H][W] arrays (full_TB.h:20-21): planar -> interleaved,
+        # resample, interleaved -> planar, all on the device.  Reported beside the headline, never `value`.
+        xp = x.permute(0, 3, 1, 2).contiguous()
+        yp = torch.empty((frames, c, d.out_h, d.out_w), device=device, dtype=x.dtype)
+        yi = torch.empty_like(y)
+        for _ in range(3):
+            ctx.resample_planar_device(d, xp.data_ptr(), yp.data_ptr(), frames, stream)
+        torch.cuda.synchronize()
+        reps = max(5, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.resample_planar_device(d, xp.data_ptr(), yp.data_ptr(), frames, stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # torch's current stream = `stream`
+        e0.record()
+        for _ in range(reps):
+            ctx.interleaved_to_planar_device(y.data_ptr(), yp.data_ptr(), d.out_w, d.out_h, c, bps, frames, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        t_out = e0.elapsed_time(e1) / reps / 1e3
+        e0.record()
+        for _ in range(reps):
+            ctx.planar_to_interleaved_device(xp.data_ptr(), yi.data_ptr(), iw, ih, c, bps, frames, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        t_in = e0.elapsed_time(e1) / reps / 1e3
+        ob, ib = frames * d.out_w * d.out_h * c * bps, frames * iw * ih * c * bps
+        extra["planar_path"] = {"value": round(frames * d.out_w * d.out_h / dt / 1e6, 1), "unit": "Mpix/s",
+                                "ms_per_batch": round(dt * 1e3, 4),
+                                "interleaved_to_planar_GBps": round(2 * ob / t_out / 1e9, 1),
+                                "planar_to_interleaved_GBps": round(2 * ib / t_in / 1e9, 1),
+                                "note": "planar in -> planar out on the device; GB/s = bytes read + written per second"}
+        ok = torch.equal(yp, y.permute(0, 3, 1, 2)) if True else None
+        extra["planar_path"]["equals_interleaved_result"] = bool(ok)
 
     if args.host_path and rank == 0:
         # PCIe-inclusive rate: host buffers in, host buffers out, through the pipelined lanczos_resample_host.

@@ -107,6 +107,19 @@ int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* i
  * Frame f starts at in + f*in_frame_stride / out + f*out_frame_stride (bytes; 0 = tightly packed). */
 int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in, void* d_out,
                             int frames, size_t in_frame_stride, size_t out_frame_stride, void* stream);
+/* ---- planar frames ----
+ * The reference's software model and testbench hold PLANAR frames, byte img_in[NUM_CHANNELS][IN_HEIGHT][IN_WIDTH] /
+ * img_out_ex[NUM_CHANNELS][OUT_HEIGHT][OUT_WIDTH] (full_TB.h:20-21), and convert from/to the interleaved stb buffer with
+ * host loops (full_TB.h:127-138, 146-165).  The same three steps on the device, asynchronous on `stream`
+ * (NULL = default stream); `frames` frames back to back, each [channels][h][w]: */
+int lanczos_planar_to_interleaved_device(lanczos_ctx* ctx, const void* d_planar, void* d_interleaved, int w, int h,
+                                         int channels, int bytes_per_sample, int frames, void* stream);
+int lanczos_interleaved_to_planar_device(lanczos_ctx* ctx, const void* d_interleaved, void* d_planar, int w, int h,
+                                         int channels, int bytes_per_sample, int frames, void* stream);
+/* img_in[C][IN_H][IN_W] -> img_out[C][OUT_H][OUT_W]: what lanczos_expected(img_in, img_out_ex) computes (full_TB.h:79-96).
+ * Whole frames only; the interleaved scratch frames live in the context (one stream at a time per context). */
+int lanczos_resample_planar_device(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in_planar, void* d_out_planar,
+                                   int frames, void* stream);
 /* The reference's call shape: sizes as plain ints, RGB8 in/out, scale = out_w/in_w reduced. */
 int lanczos_u8(lanczos_ctx* ctx, const uint8_t* in, int in_w, int in_h, int channels,
                uint8_t* out, int out_w, int out_h, int a);

@@ -30,7 +30,8 @@ ABI_SYMBOLS = [
     "lanczos_in_frame_bytes", "lanczos_out_frame_bytes", "lanczos_kernel", "lanczos_kernel_idx",
     "lanczos_taps_host", "lanczos_create", "lanczos_destroy", "lanczos_host_alloc", "lanczos_host_free",
     "lanczos_resample_host",
-    "lanczos_resample_device", "lanczos_u8", "lanczos_timing_enable", "lanczos_timing_read",
+    "lanczos_resample_device", "lanczos_planar_to_interleaved_device", "lanczos_interleaved_to_planar_device",
+    "lanczos_resample_planar_device", "lanczos_u8", "lanczos_timing_enable", "lanczos_timing_read",
     "lanczos_last_kernel", "lanczos_last_hip_error", "lanczos_force_kernel", "lanczos_strerror",
     "lanczos_version",
 ]
@@ -103,6 +104,9 @@ def _lib():
         L.lanczos_resample_host.argtypes = [c_void_p, PD, c_void_p, c_void_p, c_int]
         L.lanczos_resample_device.argtypes = [c_void_p, PD, c_void_p, c_void_p, c_int, c_size_t, c_size_t,
                                               c_void_p]
+        L.lanczos_planar_to_interleaved_device.argtypes = [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]
+        L.lanczos_interleaved_to_planar_device.argtypes = [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]
+        L.lanczos_resample_planar_device.argtypes = [c_void_p, PD, c_void_p, c_void_p, c_int, c_void_p]
         L.lanczos_u8.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int]
         L.lanczos_timing_enable.argtypes = [c_void_p, c_int]
         L.lanczos_timing_read.argtypes = [c_void_p, PI, ctypes.POINTER(c_double), ctypes.POINTER(c_double)]
@@ -250,6 +254,21 @@ class Context:
         _check(_lib().lanczos_resample_device(self._h, ctypes.byref(desc), d_in, d_out, frames,
                                               in_frame_stride, out_frame_stride, stream),
                "lanczos_resample_device")
+
+    # -- planar frames [C][H][W] (the reference's img_in / img_out_ex arrays, full_TB.h:20-21), device pointers
+    def planar_to_interleaved_device(self, d_planar, d_inter, w, h, channels, bytes_per_sample, frames, stream=None):
+        _check(_lib().lanczos_planar_to_interleaved_device(self._h, d_planar, d_inter, w, h, channels,
+                                                           bytes_per_sample, frames, stream),
+               "lanczos_planar_to_interleaved_device")
+
+    def interleaved_to_planar_device(self, d_inter, d_planar, w, h, channels, bytes_per_sample, frames, stream=None):
+        _check(_lib().lanczos_interleaved_to_planar_device(self._h, d_inter, d_planar, w, h, channels,
+                                                           bytes_per_sample, frames, stream),
+               "lanczos_interleaved_to_planar_device")
+
+    def resample_planar_device(self, desc, d_in_planar, d_out_planar, frames, stream=None):
+        _check(_lib().lanczos_resample_planar_device(self._h, ctypes.byref(desc), d_in_planar, d_out_planar, frames,
+                                                     stream), "lanczos_resample_planar_device")
 
     def timing_enable(self, on=True):
         _check(_lib().lanczos_timing_enable(self._h, 1 if on else 0), "lanczos_timing_enable")

@@ -18,6 +18,7 @@
 
 #include "../../include/lanczos_hip.h"
 #include "lanczos_fast.hpp"
+#include "lanczos_layout.hpp"
 #include "lanczos_march.hpp"
 #include "lanczos_generic.hpp"
 #include "lanczos_kernels_common.hpp"
@@ -62,6 +63,10 @@ struct lanczos_ctx {
     void* stamp_buf = nullptr;
     hipStream_t copy_in = nullptr, copy_out = nullptr;  // lanczos_resample_host pipeline
     std::vector<hipEvent_t> pipe_ev;
+    // interleaved scratch frames of lanczos_resample_planar_device
+    void* planar_in = nullptr;
+    void* planar_out = nullptr;
+    size_t planar_in_bytes = 0, planar_out_bytes = 0;
 };
 static constexpr size_t kStampBytes = 16384 * 8 * 6 * 8;
 
@@ -342,6 +347,8 @@ int lanczos_destroy(lanczos_ctx* ctx) {
     for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
     if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
     if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
+    if (ctx->planar_in) (void)hipFree(ctx->planar_in);
+    if (ctx->planar_out) (void)hipFree(ctx->planar_out);
     if (ctx->stage_in) (void)hipFree(ctx->stage_in);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -605,6 +612,69 @@ int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* i
         LZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return LANCZOS_OK;
+}
+
+// ---- planar <-> interleaved (full_TB.h:127-138, 146-165) --------------------------------------------------------
+static int layout_call(lanczos_ctx* ctx, bool to_interleaved, const void* src, void* dst, int w, int h, int channels,
+                       int bytes_per_sample, int frames, void* stream) {
+    if (!ctx || !src || !dst || w <= 0 || h <= 0 || frames <= 0) return LANCZOS_ERR_BAD_ARG;
+    if ((channels != 1 && channels != 3 && channels != 4) || (bytes_per_sample != 1 && bytes_per_sample != 2))
+        return LANCZOS_ERR_BAD_ARG;
+    if (h > 65535 || frames > 65535) return LANCZOS_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    LZ_HIP(ctx, hipSetDevice(ctx->device));
+    LZ_HIP(ctx, lz::layout_launch(to_interleaved, src, dst, w, h, channels, bytes_per_sample, frames, (hipStream_t)stream));
+    return LANCZOS_OK;
+}
+
+int lanczos_planar_to_interleaved_device(lanczos_ctx* ctx, const void* d_planar, void* d_interleaved, int w, int h,
+                                         int channels, int bytes_per_sample, int frames, void* stream) {
+    return layout_call(ctx, true, d_planar, d_interleaved, w, h, channels, bytes_per_sample, frames, stream);
+}
+
+int lanczos_interleaved_to_planar_device(lanczos_ctx* ctx, const void* d_interleaved, void* d_planar, int w, int h,
+                                         int channels, int bytes_per_sample, int frames, void* stream) {
+    return layout_call(ctx, false, d_interleaved, d_planar, w, h, channels, bytes_per_sample, frames, stream);
+}
+
+// img_in[C][IN_H][IN_W] -> img_out[C][OUT_H][OUT_W], the arrays lanczos_expected() works on (full_TB.h:20-21,79-96).
+// Whole frames only.  The interleaved scratch frames belong to the context: calls on one context must follow each
+// other in stream order (one stream at a time).
+int lanczos_resample_planar_device(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in_planar, void* d_out_planar,
+                                   int frames, void* stream) {
+    if (!ctx || !d_in_planar || !d_out_planar || frames <= 0) return LANCZOS_ERR_BAD_ARG;
+    int rc = lz::validate(d);
+    if (rc != LANCZOS_OK) return rc;
+    if (d->out_rows != 0 && !(d->out_row0 == 0 && d->out_rows == d->out_h)) return LANCZOS_ERR_UNSUPPORTED;
+    const size_t in_bytes = lanczos_in_frame_bytes(d) * frames, out_bytes = lanczos_out_frame_bytes(d) * frames;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        LZ_HIP(ctx, hipSetDevice(ctx->device));
+        if (ctx->planar_in_bytes < in_bytes) {
+            if (ctx->planar_in) (void)hipFree(ctx->planar_in);
+            ctx->planar_in = nullptr;
+            ctx->planar_in_bytes = 0;
+            LZ_HIP(ctx, hipMalloc(&ctx->planar_in, in_bytes));
+            ctx->planar_in_bytes = in_bytes;
+        }
+        if (ctx->planar_out_bytes < out_bytes) {
+            if (ctx->planar_out) (void)hipFree(ctx->planar_out);
+            ctx->planar_out = nullptr;
+            ctx->planar_out_bytes = 0;
+            LZ_HIP(ctx, hipMalloc(&ctx->planar_out, out_bytes));
+            ctx->planar_out_bytes = out_bytes;
+        }
+    }
+    rc = lanczos_planar_to_interleaved_device(ctx, d_in_planar, ctx->planar_in, d->in_w, d->in_h, d->channels,
+                                              d->bytes_per_sample, frames, stream);
+    if (rc != LANCZOS_OK) return rc;
+    lanczos_desc whole = *d;
+    whole.out_row0 = 0;
+    whole.out_rows = 0;
+    rc = lanczos_resample_device(ctx, &whole, ctx->planar_in, ctx->planar_out, frames, 0, 0, stream);
+    if (rc != LANCZOS_OK) return rc;
+    return lanczos_interleaved_to_planar_device(ctx, ctx->planar_out, d_out_planar, d->out_w, d->out_h, d->channels,
+                                                d->bytes_per_sample, frames, stream);
 }
 
 int lanczos_u8(lanczos_ctx* ctx, const uint8_t* in, int in_w, int in_h, int channels, uint8_t* out, int out_w,

@@ -470,7 +470,7 @@ __global__ __launch_bounds__((FastCfg<T, C, S, A>::NT)) void k_fast(FrameGeom g,
                         }
                         if (y >= y_first && y < y_end)  // uniform; row offset rides in the scalar soffset
                             __builtin_amdgcn_raw_buffer_store_b32(packed, orsrc, col_b,
-                                                                  (y - g.out_row0) * g.out_pitch, 0);
+                                                                  (y - g.out_row0) * g.out_pitch, LZ_STORE_AUX);
                     }
                 }
             }

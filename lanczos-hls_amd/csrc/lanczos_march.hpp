@@ -42,13 +42,6 @@
 #define LZ_MARCH_SGPR_ATTR
 #endif
 
-// Cache policy of the output stores: non-temporal + system scope (nt sc1).  The output is written once and never read
-// by the kernel; letting it allocate in L2 evicts the input rows that neighbouring workgroups re-read.  Measured
-// (interleaved A/B, config 2): default 122 us, nt 112 us, nt+sc0 112 us, nt+sc1 110 us; nt on the input LOADS: 125 us.
-#ifndef LZ_STORE_AUX
-#define LZ_STORE_AUX 18
-#endif
-
 namespace lz {
 
 template <typename T, int C, int S, int A>

@@ -275,3 +275,64 @@ def test_host_path_pipeline_with_pinned_buffers(ctx):
     assert np.array_equal(pageable, got)
     pin_in.close()
     pin_out.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# planar frames: the reference's img_in[C][H][W] / img_out_ex[C][OUT_H][OUT_W] arrays (full_TB.h:20-21) on the device
+
+
+@pytest.mark.parametrize("w,h,c,dtype", [(64, 8, 3, np.uint8), (67, 5, 3, np.uint8), (130, 9, 4, np.uint8),
+                                          (33, 7, 1, np.uint8), (62, 4, 3, np.uint16), (65, 3, 4, np.uint16),
+                                          (1920, 16, 3, np.uint8)])
+def test_planar_interleaved_conversions_match_numpy(ctx, w, h, c, dtype):
+    """full_TB.h:127-138 / 146-165 on the device: bit-exact against numpy transposes, ragged widths included."""
+    import torch
+    frames = 3
+    rng = np.random.default_rng(w * 131 + h)
+    planar = rng.integers(0, np.iinfo(dtype).max + 1, size=(frames, c, h, w)).astype(dtype)
+    tdt = torch.uint8 if dtype == np.uint8 else torch.int16
+    d_pl = torch.from_numpy(planar.view(np.uint8 if dtype == np.uint8 else np.int16)).cuda()
+    d_il = torch.zeros((frames, h, w, c), dtype=tdt, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.planar_to_interleaved_device(d_pl.data_ptr(), d_il.data_ptr(), w, h, c, planar.itemsize, frames, stream)
+    torch.cuda.synchronize()
+    got = d_il.cpu().numpy().view(dtype)
+    assert np.array_equal(got, planar.transpose(0, 2, 3, 1))
+    d_back = torch.zeros_like(d_pl)
+    ctx.interleaved_to_planar_device(d_il.data_ptr(), d_back.data_ptr(), w, h, c, planar.itemsize, frames, stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_back.cpu().numpy().view(dtype), planar)
+
+
+def test_planar_resample_matches_the_reference_digests(ctx):
+    """lanczos_resample_planar_device on the LCG frames of SURVEY.md 8(c): the FNV-1a-64 of the PLANAR device result is
+    the reference's digest -- no host-side layout change anywhere."""
+    import torch
+    with open(os.path.join(GOLD, "kat_digests.json")) as f:
+        kat = json.load(f)
+    for shape in ("1920x1080_3840x2160_2-1_a3_c3", "480x270_960x540_2-1_a4_c4", "300x200_400x266_4-3_a3_c3"):
+        iw, ih, ow, oh, sn, sd, a, c = _parse(shape)
+        planar = O.lcg_u8(c * ih * iw, 12345).reshape(1, c, ih, iw)
+        d = L.make_desc(iw, ih, c, sn, sd, a, 1, L.MODE_EXACT)
+        d_in = torch.from_numpy(planar).cuda()
+        d_out = torch.zeros((1, c, oh, ow), dtype=torch.uint8, device="cuda")
+        ctx.resample_planar_device(d, d_in.data_ptr(), d_out.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        dig = O.fnv1a64(d_out.cpu().numpy())
+        assert f"{dig:016x}" == kat["survey_8c"][shape], shape
+
+
+def test_planar_call_shape_errors(ctx):
+    import torch
+    buf = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    with pytest.raises(L.LanczosError) as e:
+        ctx.planar_to_interleaved_device(buf.data_ptr(), buf.data_ptr(), 16, 16, 2, 1, 1)   # channels = 2
+    assert e.value.code == L.ERR_BAD_ARG
+    with pytest.raises(L.LanczosError) as e:
+        ctx.interleaved_to_planar_device(0, buf.data_ptr(), 16, 16, 3, 1, 1)               # null pointer
+    assert e.value.code == L.ERR_BAD_ARG
+    d = L.make_desc(64, 64, 3, 2, 1, 3, 1, L.MODE_LSB1)
+    d.out_row0, d.out_rows = 16, 32                                                        # strips: not for planar
+    with pytest.raises(L.LanczosError) as e:
+        ctx.resample_planar_device(d, buf.data_ptr(), buf.data_ptr(), 1)
+    assert e.value.code == L.ERR_UNSUPPORTED
