@@ -102,8 +102,15 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
     size_t off_vf = off_hf + (((size_t)d->out_w * 4 + 7) & ~(size_t)7);
     size_t off_hw = off_vf + (((size_t)d->out_h * 4 + 7) & ~(size_t)7);
     size_t off_vw = off_hw + (size_t)d->out_w * taps * 8;
-    size_t total = off_vw + (size_t)d->out_h * taps * 8;
+    size_t off_xw = off_vw + (size_t)d->out_h * taps * 8;
+    size_t total = off_xw + (size_t)lz::kFastMaxS * lz::kMaxTaps * 8;
+    p->fast_ok = lz::fast_prepare(*d, p->H, p->V, &p->fast);
     std::vector<uint8_t> host(total, 0);
+    if (p->fast_ok) {  // row 0: integer phase, row ph: phase ph
+        memcpy(host.data() + off_xw, p->fast.wi, lz::kMaxTaps * 8);
+        for (int ph = 1; ph < lz::kFastMaxS; ph++)
+            memcpy(host.data() + off_xw + (size_t)ph * lz::kMaxTaps * 8, p->fast.wd[ph], lz::kMaxTaps * 8);
+    }
     memcpy(host.data() + off_hf, p->H.first.data(), (size_t)d->out_w * 4);
     memcpy(host.data() + off_vf, p->V.first.data(), (size_t)d->out_h * 4);
     memcpy(host.data() + off_hw, p->H.w.data(), (size_t)d->out_w * taps * 8);
@@ -126,7 +133,7 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
     p->dev.v_first = (const int32_t*)(b + off_vf);
     p->dev.h_w = (const double*)(b + off_hw);
     p->dev.v_w = (const double*)(b + off_vw);
-    p->fast_ok = lz::fast_prepare(*d, p->H, p->V, &p->fast);
+    p->dev.x_w = (const double*)(b + off_xw);
     ctx->plans[key] = p;
     *out = p;
     return LANCZOS_OK;

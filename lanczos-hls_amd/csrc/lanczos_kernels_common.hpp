@@ -37,6 +37,10 @@ struct TapTables {
     const double* h_w;       // [out_w][2a]
     const int32_t* v_first;  // [out_h]
     const double* v_w;       // [out_h][2a]
+    // double weights of the exact chains of the specialised kernels, in MEMORY on purpose: [0][k] integer phase
+    // (FastConsts::wi), [ph][k] phase ph (FastConsts::wd).  As kernel arguments the compiler loads them once and holds 24+
+    // SGPRs through the whole march for a path that runs for one sample in ten thousand.
+    const double* x_w;       // [1 + kFastMaxS... rows of kMaxTaps] see lanczos_fast.hpp
 };
 
 // full_TB.h:29-37: x > max -> max; x < 0 -> 0; else truncate

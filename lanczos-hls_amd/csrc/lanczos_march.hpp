@@ -339,26 +339,22 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                     const int fl = xl / S;                        // floor(x) - P0
                     const T* rp = tinT + (erow * K::IN_PITCH + F::LPB) / SB + (fl - A + 1) * C + c;
                     double sum = 0;
+                    const double* xw = t.x_w;  // exact-chain weights, read from memory here (not held in SGPRs)
                     if (xl - fl * S == 0) {                       // integer phase: the same weights everywhere
                         if (fc.skip_last) {  // flagged samples have v0 >= 1: the ~1e-33 tap at x-i = -a is inert, L(0) is 1
 #pragma unroll
                             for (int k = 0; k < TAPS - 1; k++)
-                                sum += k == A - 1 ? (double)rp[k * C] : (double)rp[k * C] * fc.wi[k];
+                                sum += k == A - 1 ? (double)rp[k * C] : (double)rp[k * C] * xw[k];
                         } else {
 #pragma unroll
-                            for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * fc.wi[k];
+                            for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * xw[k];
                         }
                     } else if (fc.phase_exact_h) {
                         // every index of a phase has the same weights: kernel arguments, no table gather on the
                         // critical path (a wave that finds a near-integer sum holds its workgroup's barrier)
                         const int ph = xl - fl * S;
 #pragma unroll
-                        for (int k = 0; k < TAPS; k++) {
-                            double w = fc.wd[1][k];
-#pragma unroll
-                            for (int q = 2; q < S; q++) w = ph == q ? fc.wd[q][k] : w;
-                            sum += (double)rp[k * C] * w;
-                        }
+                        for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * xw[ph * kMaxTaps + k];
                     } else {
                         const double* w = t.h_w + (size_t)xx * TAPS;
 #pragma unroll
