@@ -83,6 +83,7 @@ struct MarchCfg {
     static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL;
     static constexpr int NNI = F::UNIT_OUT_S - P * C;                // non-integer-phase samples of a unit
     static_assert(MS % NGRP == 0, "V groups split a tick evenly");
+    static_assert(MRG * S <= 64, "the EXACT-mode redo mask has one bit per output row of a V group");
     static_assert(NGRP == 1 || NVT % 64 == 0, "V groups must be whole waves");
     static_assert(RS >= 2 * MS + TAPS - 1, "ring holds two ticks plus the window");
     static_assert(64 % UPR == 0, "a wave covers whole unit rows");
@@ -434,6 +435,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
         int soff = (m_g * S - g.out_row0) * g.out_pitch;  // scalar byte offset of the current output row
         // two instances of the row loop: the interior one (the common case) carries no range tests at all --
         // the per-row scalar compare/select chains cost more issue slots than the arithmetic they guarded
+        unsigned long long redo_mask = 0;  // EXACT: output rows (relative to m_g * S) to redo in f64
         auto rows = [&](auto checked_c) {
         constexpr bool CHECKED = decltype(checked_c)::value;
         for (int mm = 0; mm < K::MRG; mm += TAPS) {
@@ -450,9 +452,18 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                     if (ph == 0) {
                         packed = raw[(i + A - 1) % TAPS];
                         if (EXACT && fc.vlim > 0) {
+                            // the integer-phase chain can leave v0 only if 1 <= v0 <= vlim AND (fc.tight, proven in
+                            // fast_prepare for these weights) a row two above or below is brighter than 2*v0 -- without
+                            // the second test nearly every row of a natural image would take the f64 path
+                            const float vl = (float)fc.vlim;
 #pragma unroll
-                            for (int e = 0; e < F::VEC; e++)
-                                undecided |= (((packed >> (8 * SB * e)) & F::SMASK) - 1u < (unsigned)fc.vlim);
+                            for (int e = 0; e < F::VEC; e++) {
+                                const float c0 = win[(i + A - 1) % TAPS][e];
+                                bool fl = c0 >= 1.0f && c0 <= vl;
+                                if (A >= 3 && fc.tight)
+                                    fl = fl && (win[(i + A - 3) % TAPS][e] > 2.0f * c0 || win[(i + A + 1) % TAPS][e] > 2.0f * c0);
+                                undecided |= fl;
+                            }
                         }
                     } else {
                         packed = 0;
@@ -483,21 +494,14 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                             }
                         }
                     }
+                    bool redo_row = false;
                     if (EXACT) {
-                        if (__any(undecided)) {  // wave-uniform: redo this row's dword in f64 (full_TB.h:71-75)
-                            const int yc = y < 0 ? 0 : (y < g.out_h ? y : g.out_h - 1);
-                            const double* wvd = t.v_w + (size_t)yc * TAPS;
-                            packed = 0;
-#pragma unroll
-                            for (int e = 0; e < F::VEC; e++) {
-                                double sum = 0;
-#pragma unroll
-                                for (int k = 0; k < TAPS; k++) sum += (double)win[(i + k) % TAPS][e] * wvd[k];
-                                packed |= (unsigned)store_convert<T>(sum) << (8 * SB * e);
-                            }
-                        }
+                        // a row with an undecided sample is redone in f64 AFTER the row loop, from the ring (one copy of
+                        // the f64 code, no doubles live in this loop); it is not stored here
+                        redo_row = __any(undecided);  // wave-uniform
+                        if (redo_row) redo_mask |= 1ull << ((mm + i) * S + ph);
                     }
-                    if ((!CHECKED || (m >= m_b && m < m_e && y >= y_lo && y < y_hi)) && !no_store)  // uniform
+                    if ((!CHECKED || (m >= m_b && m < m_e && y >= y_lo && y < y_hi)) && !no_store && !redo_row)  // uniform
                         __builtin_amdgcn_raw_buffer_store_b32(packed, orsrc, col_b, soff, LZ_STORE_AUX);
                     soff += g.out_pitch;
                 }
@@ -506,6 +510,28 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
         };
         if (interior) rows(std::integral_constant<bool, false>{});
         else rows(std::integral_constant<bool, true>{});
+        if (EXACT) {
+#pragma unroll 1
+            while (redo_mask) {  // uniform: the exact vertical chain of full_TB.h:71-75 for one output row
+                const int r = __builtin_ctzll(redo_mask);
+                redo_mask &= redo_mask - 1;
+                const int y = m_g * S + r, m = y / S;
+                if (!(m >= m_b && m < m_e && y >= y_lo && y < y_hi) || no_store) continue;
+                const double* wvd = t.v_w + (size_t)y * TAPS;
+                uint32_t rw[TAPS];
+#pragma unroll
+                for (int k = 0; k < TAPS; k++) rw[k] = ring(m - A + 1 + k);
+                uint32_t packed = 0;
+#pragma unroll 1
+                for (int e = 0; e < F::VEC; e++) {
+                    double sum = 0;
+#pragma unroll
+                    for (int k = 0; k < TAPS; k++) sum += (double)((rw[k] >> (8 * SB * e)) & F::SMASK) * wvd[k];
+                    packed |= (unsigned)store_convert<T>(sum) << (8 * SB * e);
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(packed, orsrc, col_b, (y - g.out_row0) * g.out_pitch, LZ_STORE_AUX);
+            }
+        }
     };
 
     // diagnostic build only: residency census -- when and where (XCC / SE / CU) this workgroup ran
