@@ -513,8 +513,8 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
         const int samples_w = d->out_w * d->channels;
         dim3 grid((samples_w + 127) / 128, frames);
 #define LZ_PREFIX(T, TAPS)                                                                                       \
-    hipLaunchKernelGGL((lz::k_prefix<T, TAPS>), grid, dim3(128), 0, stream, g, p->dev, p->prefix.K, p->prefix.M, \
-                       p->prefix.M2)
+    hipLaunchKernelGGL((lz::k_prefix<T, TAPS>), grid, dim3(128), (size_t)(p->prefix.M + p->prefix.M2) * 128 * sizeof(T), stream, g, \
+                       p->dev, p->prefix.K, p->prefix.M, p->prefix.M2)
         if (d->bytes_per_sample == 1) {
             if (d->a == 2) LZ_PREFIX(uint8_t, 4);
             else if (d->a == 3) LZ_PREFIX(uint8_t, 6);

@@ -110,8 +110,13 @@ __global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K,
     const uint8_t* in_f = g.in + (size_t)frame * g.in_frame_stride;
     uint8_t* out_f = g.out + (size_t)frame * g.out_frame_stride;
 
-    T h[kMaxPrefixRows + kMaxTaps];  // H-pass rows 0..M2-1 of this column
-    T o[kMaxPrefixRows + kMaxTaps];  // output rows 0..M-1 of this column
+    // H-pass rows 0..M2-1 and output rows 0..M-1 of this column.  In LDS, not in per-thread arrays: the recurrence
+    // indexes them with run-time row numbers, and a register array indexed that way lands in scratch memory
+    // (the first version of this kernel: 146 VGPRs + 160 B of scratch per lane).
+    extern __shared__ __attribute__((aligned(16))) uint8_t prefix_smem[];  // (M2 + M) rows of 128 samples
+    T(*hs)[128] = (T(*)[128])prefix_smem;
+    T(*os)[128] = hs + M2;
+    const int tl = threadIdx.x;
 
     {   // horizontal pass of the rows the prefix reads (full_TB.h:55-65)
         const int xx = j / C, c = j - xx * C;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K,
             double sum = 0;
 #pragma unroll
             for (int k = 0; k < TAPS; k++) sum += (double)v[k] * w[k];
-            h[r] = store_convert<T>(sum);
+            hs[r][tl] = store_convert<T>(sum);
         }
     }
     // full_TB.h:69-76, xx descending: a tap at row i > xx sees the value already written there
@@ -146,15 +151,15 @@ __global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K,
         for (int k = 0; k < TAPS; k++) {
             int i = first + k;
             i = i < 0 ? 0 : (i > g.in_h - 1 ? g.in_h - 1 : i);  // weight 0 outside
-            const T v = i > xx ? o[i] : h[i];
+            const T v = i > xx ? os[i][tl] : hs[i][tl];
             sum += (double)v * wv[k];
         }
-        o[xx] = store_convert<T>(sum);
+        os[xx][tl] = store_convert<T>(sum);
     }
     for (int xx = 0; xx < K; xx++) {
         if (xx < g.out_row0 || xx >= g.out_row0 + g.out_rows) continue;
         T* orow = (T*)(out_f + (size_t)(xx - g.out_row0) * g.out_pitch);
-        orow[j] = o[xx];
+        orow[j] = os[xx][tl];
     }
 }
 
