@@ -1,7 +1,12 @@
 // sim_tb_example.cpp -- a caller shaped like the reference's testbench (full_TB.h:99-180) linked against the
 // MI355X library through hls_compat.hpp: pack pixels into stream_in, call lanczos(stream_in, stream_out), read
-// stream_out back.  Build: see Makefile target `sim_tb_example`; run on a machine with a GPU:
-//   ./sim_tb_example in.png observed.png
+// stream_out back, print "RMS err" against the expected image and write the expected and the observed PNG under the
+// testbench's names, "<dir>/WxH->WxH_N|D_A-expected.png" / "...-observed.png" (full_TB.h:142-177).  The expected image
+// here is the library's own bit-exact mode (LANCZOS_MODE_EXACT = lanczos_expected() bit for bit, proven by tests/);
+// the observed one is what lanczos(stream_in, stream_out) returns (default mode, within +-1).
+// Build: Makefile target `sim_tb_example`; run on a machine with a GPU:   ./sim_tb_example in.png out_dir/
+#include <cmath>
+#include <string>
 #define IN_WIDTH 256
 #define IN_HEIGHT 256
 #define OUT_WIDTH 512
@@ -39,5 +44,33 @@ int main(int argc, char* argv[]) {
         stream_out.read(r_pixel);
         for (int j = 0; j < NUM_CHANNELS; j++) ob[(size_t)i * NUM_CHANNELS + j] = r_pixel.channel[j];
     }
-    return lz_image_write_png(argv[2], OUT_WIDTH, OUT_HEIGHT, NUM_CHANNELS, ob.data(), OUT_WIDTH * NUM_CHANNELS) ? 0 : EXIT_FAILURE;
+    // expected: the software model's result, here from the bit-exact mode of the same library
+    std::vector<uint8_t> ex(ob.size());
+    {
+        lanczos_ctx* ctx = nullptr;
+        lanczos_desc d;
+        if (lanczos_create(&ctx, 0) != LANCZOS_OK ||
+            lanczos_desc_init(&d, IN_WIDTH, IN_HEIGHT, NUM_CHANNELS, 1, SCALE_N, SCALE_D, LANCZOS_A) != LANCZOS_OK)
+            return EXIT_FAILURE;
+        d.mode = LANCZOS_MODE_EXACT;
+        const int rc = lanczos_resample_host(ctx, &d, img, ex.data(), 1);
+        lanczos_destroy(ctx);
+        if (rc != LANCZOS_OK) {
+            printf("lanczos: %s\n", lanczos_strerror(rc));
+            return EXIT_FAILURE;
+        }
+    }
+    double err = 0;
+    for (size_t i = 0; i < ob.size(); i++) {
+        const int diff = (int)ex[i] - (int)ob[i];
+        err += (double)diff * diff;
+    }
+    printf("RMS err: %.3f\n", sqrt(err / (double)ob.size()));
+    char name[160];
+    const std::string dir = argv[2];
+    snprintf(name, sizeof(name), "%dx%d->%dx%d_%d|%d_%d-", IN_WIDTH, IN_HEIGHT, OUT_WIDTH, OUT_HEIGHT, SCALE_N, SCALE_D, LANCZOS_A);
+    const std::string base = dir + (dir.empty() || dir.back() == '/' ? "" : "/") + name;
+    const bool ok = lz_image_write_png((base + "expected.png").c_str(), OUT_WIDTH, OUT_HEIGHT, NUM_CHANNELS, ex.data(), OUT_WIDTH * NUM_CHANNELS) &&
+                    lz_image_write_png((base + "observed.png").c_str(), OUT_WIDTH, OUT_HEIGHT, NUM_CHANNELS, ob.data(), OUT_WIDTH * NUM_CHANNELS);
+    return ok ? 0 : EXIT_FAILURE;
 }

@@ -53,11 +53,25 @@ def test_harness_config1_end_to_end(tmp_path):
     want = O.expected_hwc_u8(cfg, img)
     src = tmp_path / "in.ppm"
     _write_ppm(str(src), img)
-    for exe, args in (("lanczos_upscale", ["--scale", "2", "--a", "2", "--exact"]), ("sim_tb_example", [])):
-        dst = tmp_path / (exe + ".png")
-        r = subprocess.run([os.path.join(PKG, exe), str(src), str(dst)] + args, capture_output=True, text=True)
-        assert r.returncode == 0, r.stdout + r.stderr
-        assert "Scale:2/1, WIDTHS 256 -> 512" in r.stdout            # full_TB.h:124
-        got = _read_png(str(dst))
-        diff = np.abs(got.astype(int) - want.astype(int))
-        assert got.shape == want.shape and diff.max() <= (0 if "--exact" in args else 1), exe
+    # the plain C harness
+    dst = tmp_path / "lanczos_upscale.png"
+    r = subprocess.run([os.path.join(PKG, "lanczos_upscale"), str(src), str(dst), "--scale", "2", "--a", "2", "--exact"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Scale:2/1, WIDTHS 256 -> 512" in r.stdout                # full_TB.h:124
+    assert np.array_equal(_read_png(str(dst)), want)
+    # the testbench-shaped caller: lanczos(stream_in, stream_out), "RMS err", expected + observed PNGs named as in
+    # full_TB.h:166-177
+    outdir = tmp_path / "img"
+    outdir.mkdir()
+    r = subprocess.run([os.path.join(PKG, "sim_tb_example"), str(src), str(outdir)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Scale:2/1, WIDTHS 256 -> 512" in r.stdout and "RMS err: " in r.stdout
+    rms = float(r.stdout.split("RMS err: ")[1].split()[0])
+    base = "256x256->512x512_2|1_2-"
+    expected = _read_png(str(outdir / (base + "expected.png")))
+    observed = _read_png(str(outdir / (base + "observed.png")))
+    assert np.array_equal(expected, want)                             # the bit-exact mode IS lanczos_expected()
+    diff = np.abs(observed.astype(int) - want.astype(int))
+    assert observed.shape == want.shape and diff.max() <= 1
+    assert abs(rms - float(np.sqrt((diff.astype(float) ** 2).mean()))) < 1e-3
