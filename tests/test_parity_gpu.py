@@ -336,3 +336,33 @@ def test_planar_call_shape_errors(ctx):
     with pytest.raises(L.LanczosError) as e:
         ctx.resample_planar_device(d, buf.data_ptr(), buf.data_ptr(), 1)
     assert e.value.code == L.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("pad_in,pad_out", [(0, 0), (4096, 8192), (48, 80), (20, 12)])
+def test_frame_strides_and_kernel_families(ctx, pad_in, pad_out):
+    """Frames that are not tightly packed (in/out frame strides): 16-byte multiples keep the marching kernel, other
+    strides fall back to the tile kernel -- same results either way, and the padding stays untouched."""
+    import torch
+    w, h, c, sn, a, frames = 208, 96, 3, 2, 3, 5
+    d = L.make_desc(w, h, c, sn, 1, a, 1, L.MODE_EXACT)
+    imgs = [P.gradient_noise(h, w, c, seed=70 + f) for f in range(frames)]
+    cfg = O.cfg(w, h, d.out_w, d.out_h, c, a, sn, 1)
+    want = [O.expected_hwc_u8(cfg, im) for im in imgs]
+    in_fb, out_fb = w * h * c, d.out_w * d.out_h * c
+    in_stride, out_stride = in_fb + pad_in, out_fb + pad_out
+    host_in = np.full(frames * in_stride, 0xA5, dtype=np.uint8)
+    for f in range(frames):
+        host_in[f * in_stride:f * in_stride + in_fb] = imgs[f].reshape(-1)
+    d_in = torch.from_numpy(host_in).cuda()
+    d_out = torch.full((frames * out_stride,), 0x5A, dtype=torch.uint8, device="cuda")
+    for mode in (L.MODE_EXACT, L.MODE_LSB1):
+        d.mode = mode
+        d_out.fill_(0x5A)
+        ctx.resample_device(d, d_in.data_ptr(), d_out.data_ptr(), frames, in_stride, out_stride,
+                            torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for f in range(frames):
+            g = got[f * out_stride:f * out_stride + out_fb].reshape(d.out_h, d.out_w, c)
+            _cmp(g, want[f], mode, f"frame {f} pads {pad_in}/{pad_out}")
+            assert np.all(got[f * out_stride + out_fb:(f + 1) * out_stride] == 0x5A), "padding between frames was written"
