@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""tests/soak_gpu.py [seconds] -- randomized parity soak on a GPU box (test infrastructure, not collected by pytest).
+
+Random shapes / channel counts / scales / a / input generators, both parity modes, compared with the CPU oracle
+(oracle/, the restated reference software path).  Prints one line per failure and a summary; exit code 1 on any
+mismatch.  Purpose: statistical cover for the f32 error bound (near-integer fix-ups) and the integer-phase flip filter
+beyond the fixed shapes of test_parity_gpu.py."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import lanczos_hls_amd as L  # noqa: E402
+import oracle_lib as O  # noqa: E402
+import patterns as P  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    rng = np.random.default_rng(20261004)
+    ctx = L.Context(0)
+    gens = [P.noise, P.dark_noise, P.gradient_noise, lambda h, w, c, seed=0: P.blocks(h, w, c)]
+    t0 = time.time()
+    n = bad = 0
+    samples = 0
+    families = {}
+    while time.time() - t0 < budget:
+        c = int(rng.choice([1, 3, 3, 3, 4]))
+        sn, sd = [(2, 1), (2, 1), (3, 1), (3, 2), (4, 3), (5, 2)][int(rng.integers(0, 6))]
+        a = int(rng.choice([2, 3, 3, 4]))
+        # widths: mostly multiples that keep rows 16-byte multiples (marching kernel), sometimes ragged
+        w = int(rng.integers(3, 60)) * 16 if rng.random() < 0.7 else int(rng.integers(40, 700))
+        h = int(rng.integers(24, 260))
+        if (w * sn) % sd or (h * sn) % sd:
+            continue
+        gen = gens[int(rng.integers(0, len(gens)))]
+        img = gen(h, w, c, seed=int(rng.integers(0, 1 << 30)))
+        cfg = O.cfg(w, h, w * sn // sd, h * sn // sd, c, a, sn, sd)
+        want = O.expected_hwc_u8(cfg, img, threads=16)
+        for mode in (L.MODE_EXACT, L.MODE_LSB1):
+            got = ctx.resample(img, sn, sd, a, mode)
+            diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+            ok = diff.max() == 0 if mode == L.MODE_EXACT else diff.max() <= 1
+            families[ctx.last_kernel()] = families.get(ctx.last_kernel(), 0) + 1
+            if not ok:
+                bad += 1
+                gname = getattr(gen, "__name__", "blocks")
+                print(f"MISMATCH mode={mode} {w}x{h} c={c} {sn}/{sd} a={a} gen={gname} max={diff.max()} "
+                      f"count={np.count_nonzero(diff > (0 if mode == L.MODE_EXACT else 1))}", flush=True)
+        n += 1
+        samples += want.size
+        if n % 50 == 0:
+            print(f"... {n} cases, {samples / 1e6:.0f} M samples, {bad} failures, {time.time() - t0:.0f} s", flush=True)
+    print(f"soak: {n} cases, {samples / 1e6:.0f} M output samples per mode, kernel families {families}, {bad} failures")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
