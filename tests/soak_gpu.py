@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/soak_gpu.py [seconds] -- randomized parity soak on a GPU box (test infrastructure, not collected by pytest).
+"""tests/soak_gpu.py [seconds] [share of 16-bit cases] -- randomized parity soak on a GPU box (test infrastructure, not collected by pytest).
 
 Random shapes / channel counts / scales / a / input generators, both parity modes, compared with the CPU oracle
 (oracle/, the restated reference software path).  Prints one line per failure and a summary; exit code 1 on any
@@ -23,6 +23,7 @@ import patterns as P  # noqa: E402
 
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    u16_share = float(sys.argv[2]) if len(sys.argv) > 2 else 0.2
     rng = np.random.default_rng(20261004)
     ctx = L.Context(0)
     gens = [P.noise, P.dark_noise, P.gradient_noise, lambda h, w, c, seed=0: P.blocks(h, w, c)]
@@ -40,9 +41,16 @@ def main():
         if (w * sn) % sd or (h * sn) % sd:
             continue
         gen = gens[int(rng.integers(0, len(gens)))]
-        img = gen(h, w, c, seed=int(rng.integers(0, 1 << 30)))
         cfg = O.cfg(w, h, w * sn // sd, h * sn // sd, c, a, sn, sd)
-        want = O.expected_hwc_u8(cfg, img, threads=16)
+        if u16_share > 0 and rng.random() < u16_share:  # 16-bit samples: the build's generalisation (clamp 65535)
+            gen = P.noise
+            img = P.noise(h, w, c, seed=int(rng.integers(0, 1 << 30)), dtype=np.uint16)
+            if rng.random() < 0.5:
+                img = (img >> int(rng.integers(4, 12))).astype(np.uint16)  # darker: integer-phase candidates
+            want = O.expected_hwc_u16(cfg, img, threads=16)
+        else:
+            img = gen(h, w, c, seed=int(rng.integers(0, 1 << 30)))
+            want = O.expected_hwc_u8(cfg, img, threads=16)
         for mode in (L.MODE_EXACT, L.MODE_LSB1):
             got = ctx.resample(img, sn, sd, a, mode)
             diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
