@@ -107,11 +107,14 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     // XCD-aware placement.  Workgroups go round-robin to the 8 XCDs by linear id (verified: profiles/round1c census),
     // and every XCD has its own L2.  A strip's 16-byte halo chunks pull in its neighbours' 128-byte lines, so with the
     // natural order (neighbouring strips on different XCDs) every input line is fetched 5/3 times (measured: 164 MB read
-    // for 99.5 MB of input).  Remapped, the ids an XCD receives cover whole frames: neighbours share an L2.
+    // for 99.5 MB of input).  Remapped, the ids an XCD receives are consecutive (whole frames in the benchmark's launch):
+    // neighbours share an L2.
     const int nwg = gridDim.x * gridDim.y, wid = blockIdx.y * gridDim.x + blockIdx.x;
     // (Measured, config 2: read traffic 160 MB -> 98.9 MB per launch, 112.7 -> 108.5 us.  Sharing an XCD only among the
     // strips of one band and spreading the bands round-robin was slower: 119 us.)  Profiling bit 4096 = natural order.
-    const int lid = (nwg & 7) == 0 && !(g.debug_skip & 4096) ? (wid & 7) * (nwg >> 3) + (wid >> 3) : wid;
+    // XCD x receives the ids x, x+8, ...: (nwg - x + 7) / 8 of them; they are renumbered consecutively behind XCD x-1's.
+    const int xcd = wid & 7, xq = nwg >> 3, xr = nwg & 7;
+    const int lid = !(g.debug_skip & 4096) ? xcd * xq + (xcd < xr ? xcd : xr) + (wid >> 3) : wid;
     const int frame = lid / (int)gridDim.x;
     const int tx = (lid - frame * (int)gridDim.x) % strips;
     const int chunk = (lid - frame * (int)gridDim.x) / strips;
