@@ -180,9 +180,19 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    # Pass A (untimed for `value`): the same K steps with the library's HIP events around every kernel -> roofline.
     sync_all()
     ctx.timing_enable(True)
     ctx.timing_read()  # reset
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    launches, main_ms, prefix_ms = ctx.timing_read()
+    ctx.timing_enable(False)
+
+    # Pass B (the timed region): exactly K steps, no instrumentation, barrier + synchronize on both sides.  (Replaying
+    # one captured step as a HIP graph was measured too: 0.144-0.150 ms per step against 0.114 ms of plain launches.)
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -194,8 +204,6 @@ def main():
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    launches, main_ms, prefix_ms = ctx.timing_read()
-    ctx.timing_enable(False)
 
     out_pix_step = frames * d.out_w * d.out_h  # per GPU
     value = world * out_pix_step * args.steps / elapsed / 1e6
