@@ -482,14 +482,25 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
         LZ_HIP(ctx, hipEventRecord(ev0, stream));
     }
 
+    bool prefix_fused = false;
     bool use_fast = p->fast_ok && ctx->force != LANCZOS_KERNEL_GENERIC &&
                     lz::fast_supports(*d, g);
     if (ctx->force == LANCZOS_KERNEL_FAST && !use_fast) return LANCZOS_ERR_UNSUPPORTED;
     if (use_fast) {
         // LANCZOS_TILE_KERNEL=1 selects the older tile-per-workgroup kernel (kept for A/B measurements)
         static const bool use_tile = getenv("LANCZOS_TILE_KERNEL") && atoi(getenv("LANCZOS_TILE_KERNEL")) != 0;
-        hipError_t e = (use_tile || !lz::march_supports(g)) ? lz::fast_launch(*d, g, p->dev, p->fast, stream)
-                                                             : lz::march_launch(*d, g, p->dev, p->fast, stream);
+        hipError_t e;
+        if (use_tile || !lz::march_supports(g)) {
+            e = lz::fast_launch(*d, g, p->dev, p->fast, stream);
+        } else {
+            lz::FrameGeom gm = g;
+            if (has_prefix) {  // ask the marching launch to carry the prefix rows too (no separate k_prefix launch)
+                gm.prefix_K = p->prefix.K;
+                gm.prefix_M = p->prefix.M;
+                gm.prefix_M2 = p->prefix.M2;
+            }
+            e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &prefix_fused);
+        }
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
             return LANCZOS_ERR_HIP;
@@ -509,7 +520,7 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
     }
     if (ev1) LZ_HIP(ctx, hipEventRecord(ev1, stream));
 
-    if (has_prefix) {
+    if (has_prefix && !prefix_fused) {
         const int samples_w = d->out_w * d->channels;
         dim3 grid((samples_w + 127) / 128, frames);
 #define LZ_PREFIX(T, TAPS)                                                                                       \

@@ -29,6 +29,10 @@ struct FrameGeom {
     int skip_rows;        // output rows < skip_rows are left to the in-place prefix kernel
     int frames;
     unsigned long long* stamps;  // diagnostic builds only: per-wave cycle sums (see k_march STAMP)
+    // k_march only: the grid is 1-D, `n_main` marching workgroups (`wg_per_frame` per frame) followed by
+    // `prefix_blocks_per_frame` workgroups per frame that produce output rows [0, prefix_K) (the in-place prefix, see
+    // k_prefix); prefix_K == 0: a separate k_prefix launch does that
+    int n_main, wg_per_frame, prefix_blocks_per_frame, prefix_K, prefix_M, prefix_M2;
     int debug_skip;       // ablation bits for profiling builds (0 in production): 1 H-pass, 2 fix-up, 4 V-pass, 8 stores, 16 loads
 };
 

@@ -90,7 +90,10 @@ struct MarchCfg {
     static_assert(F::UNIT_OUT_S <= 64 && MS <= 32 && UPR <= 32, "worklist entry = row:5 | unit:5 | sample:6");
 };
 
-template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false>
+// RIDE: the launch also carries the in-place prefix rows as extra workgroups behind the marching ones (small batches:
+// no separate k_prefix launch).  That variant rebuilds its per-lane indices every tick to stay inside the register
+// budget; the batch variant (RIDE = false) holds them in registers, which is 2-3 % faster when the chip is full.
+template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
 __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc,
                                                                       int chunk_rows) {
     using K = MarchCfg<T, C, S, A>;
@@ -103,21 +106,90 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     const int lane = tid & 63;
     uint16_t* wlw = (uint16_t*)(smem + K::LDS_TIN + K::LDS_HBUF) + wave * K::WLW;  // this wave's list
 
+    // =================================================================== the in-place prefix rows (extra workgroups)
+    // Output rows [0, K) are a short sequential recurrence per sample column (full_TB.h:67-77; k_prefix).  As a launch of
+    // their own they cost 8 us + a 2-5 us gap per step whatever the batch: a chain of dependent memory round trips.  Here
+    // they ride at the END of the marching grid: these workgroups have the highest ids, are dispatched last and run in
+    // the slots the first marching workgroups free, beside the tail of the march.  One column per thread, f64, the
+    // arithmetic of k_prefix; everything is read through a laundered kernel-argument pointer so that nothing this path
+    // needs is carried in SGPRs by the marching workgroups (that cost 14 spill reloads per tick when tried).
+    if (RIDE && (int)blockIdx.x >= g.n_main) {
+        const uint8_t* ka = (const uint8_t*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const FrameGeom& G = *(const FrameGeom*)ka;
+        const TapTables& TT = *(const TapTables*)(ka + ((sizeof(FrameGeom) + 7) & ~(size_t)7));
+        static_assert(alignof(FrameGeom) == 8 && alignof(TapTables) == 8, "kernel-argument layout: g, then t, both 8-byte aligned");
+        const int pw = (int)blockIdx.x - G.n_main;
+        const int pframe = pw / G.prefix_blocks_per_frame;
+        const int j = (pw - pframe * G.prefix_blocks_per_frame) * K::NT + tid;
+        if (j >= G.out_w * C) return;
+        const int PK = G.prefix_K, PM = G.prefix_M, PM2 = G.prefix_M2;
+        T* hs = (T*)smem;                 // [PM2][NT]
+        T* os = hs + PM2 * K::NT;         // [PM][NT]
+        const uint8_t* pin = G.in + (size_t)pframe * G.in_frame_stride;
+        uint8_t* pout = G.out + (size_t)pframe * G.out_frame_stride;
+        {   // horizontal pass of the rows the prefix reads (full_TB.h:55-65)
+            const int xx = j / C, c = j - xx * C;
+            const int first = TT.h_first[xx];
+            int idx[TAPS];
+            double w[TAPS];
+#pragma unroll
+            for (int k = 0; k < TAPS; k++) {
+                int i = first + k;
+                i = i < 0 ? 0 : (i > G.in_w - 1 ? G.in_w - 1 : i);  // weight is 0 there
+                idx[k] = i * C + c;
+                w[k] = TT.h_w[(size_t)xx * TAPS + k];
+            }
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+            for (int r = 0; r < PM2; r++) {  // (kept scalar and rolled: this path must not set the kernel's register count)
+                const T* rowp = (const T*)(pin + (size_t)(r - G.in_row0) * G.in_pitch);
+                T v[TAPS];
+#pragma unroll
+                for (int k = 0; k < TAPS; k++) v[k] = rowp[idx[k]];
+                double sum = 0;
+#pragma unroll
+                for (int k = 0; k < TAPS; k++) sum += (double)v[k] * w[k];
+                hs[r * K::NT + tid] = store_convert<T>(sum);
+            }
+        }
+        // full_TB.h:69-76, xx descending: a tap at row i > xx sees the value already written there
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+        for (int xx = PM - 1; xx >= 0; xx--) {
+            const int first = TT.v_first[xx];
+            const double* wvp = TT.v_w + (size_t)xx * TAPS;
+            double sum = 0;
+#pragma unroll
+            for (int k = 0; k < TAPS; k++) {
+                int i = first + k;
+                i = i < 0 ? 0 : (i > G.in_h - 1 ? G.in_h - 1 : i);  // weight 0 outside
+                const T v = i > xx ? os[i * K::NT + tid] : hs[i * K::NT + tid];
+                sum += (double)v * wvp[k];
+            }
+            os[xx * K::NT + tid] = store_convert<T>(sum);
+        }
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+        for (int xx = 0; xx < PK; xx++) {
+            if (xx < G.out_row0 || xx >= G.out_row0 + G.out_rows) continue;
+            ((T*)(pout + (size_t)(xx - G.out_row0) * G.out_pitch))[j] = os[xx * K::NT + tid];
+        }
+        return;
+    }
+
     const int strips = (g.out_w + F::TWP_OUT - 1) / F::TWP_OUT;
     // XCD-aware placement.  Workgroups go round-robin to the 8 XCDs by linear id (verified: profiles/round1c census),
     // and every XCD has its own L2.  A strip's 16-byte halo chunks pull in its neighbours' 128-byte lines, so with the
     // natural order (neighbouring strips on different XCDs) every input line is fetched 5/3 times (measured: 164 MB read
     // for 99.5 MB of input).  Remapped, the ids an XCD receives are consecutive (whole frames in the benchmark's launch):
     // neighbours share an L2.
-    const int nwg = gridDim.x * gridDim.y, wid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int nwg = g.n_main, wid = blockIdx.x;
     // (Measured, config 2: read traffic 160 MB -> 98.9 MB per launch, 112.7 -> 108.5 us.  Sharing an XCD only among the
     // strips of one band and spreading the bands round-robin was slower: 119 us.)  Profiling bit 4096 = natural order.
     // XCD x receives the ids x, x+8, ...: (nwg - x + 7) / 8 of them; they are renumbered consecutively behind XCD x-1's.
     const int xcd = wid & 7, xq = nwg >> 3, xr = nwg & 7;
     const int lid = !(g.debug_skip & 4096) ? xcd * xq + (xcd < xr ? xcd : xr) + (wid >> 3) : wid;
-    const int frame = lid / (int)gridDim.x;
-    const int tx = (lid - frame * (int)gridDim.x) % strips;
-    const int chunk = (lid - frame * (int)gridDim.x) / strips;
+    const int frame = lid / g.wg_per_frame;
+    const int tx = (lid - frame * g.wg_per_frame) % strips;
+    const int chunk = (lid - frame * g.wg_per_frame) / strips;
 
     // rows: m = floor(y/S) is the input row an output row hangs on.  This workgroup owns m in [m_b, m_e).
     const int y_lo = g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows;  // first output row stored at all
@@ -144,10 +216,14 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
         const_cast<uint8_t*>(in_f), 0, (unsigned)(g.in_rows * g.in_pitch), 0x00020000);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 pre[K::LOAD_IT];
+    // (RIDE: per-lane indices are rebuilt every tick from an opaque copy of the thread id -- a handful of instructions --
+    // instead of being held in registers across the other phases: the kernel sits on its 72-VGPR budget.)
     auto issue_loads = [&](int tick) {
+        int t1 = tid;
+        if (RIDE) asm volatile("" : "+v"(t1));
 #pragma unroll
         for (int it = 0; it < K::LOAD_IT; it++) {
-            const int idx = tid + it * K::NT;
+            const int idx = t1 + it * K::NT;
             const int row = idx / K::CPR, ch = idx - row * K::CPR;
             const int gr = hb + tick * K::MS + row;
             const int gb = tile_gb0 + 16 * ch;
@@ -187,8 +263,10 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     auto hpass = [&](int tick) {
         const uint8_t* tin = smem + (tick & 1) * K::TIN_BYTES;
         const int h0 = hb + tick * K::MS;           // first H row of the tick
-        const int row = tid / K::UPR, u = tid % K::UPR;
-        const bool unit_ok = tid < K::NU && h0 + row <= h_last && !(g.debug_skip & 1);
+        int t3 = tid;
+        if (RIDE) asm volatile("" : "+v"(t3));
+        const int row = t3 / K::UPR, u = t3 % K::UPR;
+        const bool unit_ok = t3 < K::NU && h0 + row <= h_last && !(g.debug_skip & 1);
         uint32_t im = 0;      // undecided integer-phase samples: bit (8*e*SB + i) <-> own input sample i*VEC + e
         bool near = false;    // some non-integer-phase sample of the unit is within eps of an integer
         if (unit_ok) {
@@ -404,16 +482,19 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     };
 
     // =================================================================== VPASS of one tick
-    const int grp = K::NGRP == 1 ? (tid < K::NVT ? 0 : 1) : wave * 64 / K::NVT;
-    const int col = tid - grp * K::NVT;
-    const unsigned col_b = (unsigned)(tx * F::TWB_OUT + col * 4);
-    const bool col_ok = grp < K::NGRP && col_b + 4 <= (unsigned)(g.out_w * C * SB);
+    const int grp_w = K::NGRP == 1 ? 0 : wave * 64 / K::NVT;  // the wave's V group (NGRP > 1: groups are whole waves)
     const __amdgpu_buffer_rsrc_t orsrc =
         __builtin_amdgcn_make_buffer_rsrc(out_f, 0, (unsigned)(g.out_rows * g.out_pitch), 0x00020000);
     float vbias = (SB == 1 && !EXACT) ? fc.vbias_rne : fc.bias;
     asm volatile("" : "+v"(vbias));
 
     auto vpass = [&](int tick) {
+        int t2 = tid;
+        if (RIDE) asm volatile("" : "+v"(t2));
+        const int grp = K::NGRP == 1 ? (t2 < K::NVT ? 0 : 1) : grp_w;
+        const int col = t2 - grp * K::NVT;
+        const unsigned col_b = (unsigned)(tx * F::TWB_OUT + col * 4);
+        const bool col_ok = grp < K::NGRP && col_b + 4 <= (unsigned)(g.out_w * C * SB);
         if (!col_ok || (g.debug_skip & 4)) return;
         constexpr int HP = K::H_PITCH / 4;
         // m handled this tick: [m_lo, m_lo + MS) with m_lo = m_b - (2a-1) + tick*MS; this group's share:
@@ -589,11 +670,11 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
         }
     }
     if (STAMP && g.stamps && lane == 0) {
-        unsigned long long* dst = g.stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * K::NWAVES + wave) * 6;
+        unsigned long long* dst = g.stamps + ((size_t)blockIdx.x * K::NWAVES + wave) * 6;
         for (int i = 0; i < 5; i++) dst[i] = tsum[i];
         dst[5] = (unsigned long long)ticks;
         if (wave == 0) {  // second half of the buffer: one record per workgroup
-            unsigned long long* c = g.stamps + (size_t)16384 * 8 * 3 + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 3;
+            unsigned long long* c = g.stamps + (size_t)16384 * 8 * 3 + (size_t)blockIdx.x * 3;
             c[0] = census_t0;
             c[1] = __builtin_amdgcn_s_memrealtime();
             c[2] = ((unsigned long long)census_xcc << 32) | census_hw;
@@ -623,10 +704,20 @@ inline int march_chunk_rows(int m_rows, int strips, int frames, int ms, int slot
 }
 
 template <typename T, int C, int S, int A>
-inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g, const TapTables& t,
-                                 const FastConsts& fc, hipStream_t stream) {
+inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, const TapTables& t,
+                                 const FastConsts& fc, hipStream_t stream, bool* prefix_fused) {
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
+    FrameGeom g = g_in;
+    // g.prefix_K > 0 asks for the in-place prefix rows to ride on this launch (extra workgroups behind the marching
+    // ones); that needs a main launch at all and the row arrays to fit the workgroup's LDS -- otherwise the caller
+    // launches k_prefix
+    static const bool separate_prefix = getenv("LANCZOS_SEPARATE_PREFIX") && atoi(getenv("LANCZOS_SEPARATE_PREFIX")) != 0;
+    if (g.prefix_K > 0 &&
+        (separate_prefix || (size_t)(g.prefix_M + g.prefix_M2) * K::NT * sizeof(T) > (size_t)K::LDS_BYTES ||
+         g.out_row0 + g.out_rows <= (g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows)))
+        g.prefix_K = g.prefix_M = g.prefix_M2 = 0;
+    *prefix_fused = g.prefix_K > 0;
     const int strips = (g.out_w + F::TWP_OUT - 1) / F::TWP_OUT;
     const int y_lo = g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows;
     const int y_hi = g.out_row0 + g.out_rows;
@@ -655,7 +746,21 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g, cons
     }
     const int chunk_rows = march_chunk_rows(m_rows, strips, g.frames, K::MS, slots[exact_][dev_]);
     const int chunks = (m_rows + chunk_rows - 1) / chunk_rows;
-    dim3 grid(strips * chunks, g.frames);
+    g.wg_per_frame = strips * chunks;
+    g.n_main = g.wg_per_frame * g.frames;
+    g.prefix_blocks_per_frame = g.prefix_K > 0 ? (g.out_w * C + K::NT - 1) / K::NT : 0;
+    // Measured (config 2, ms per step riding / separate): 1 frame 0.0198 / 0.0253, 2: 0.0281 / 0.0335, 4: 0.0464 / 0.0525,
+    // 8: 0.0687 / 0.0729, 16: 0.117-0.120 / 0.114-0.116 -- past about one prefix workgroup per CU they slow the march
+    // down more than the launch they replace.
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || cus < 1) cus = 256;
+        if (g.prefix_blocks_per_frame * g.frames > cus) {
+            g.prefix_K = g.prefix_M = g.prefix_M2 = g.prefix_blocks_per_frame = 0;
+            *prefix_fused = false;
+        }
+    }
+    dim3 grid(g.n_main + g.prefix_blocks_per_frame * g.frames);
     static const int extra_lds = getenv("LANCZOS_EXTRA_LDS") ? atoi(getenv("LANCZOS_EXTRA_LDS")) : 0;  // occupancy experiments
     static bool attr_done[2][64] = {};
     const bool exact = d.mode == LANCZOS_MODE_EXACT;
@@ -669,6 +774,23 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g, cons
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + extra_lds);
         if (e != hipSuccess) return e;
         attr_done[exact][dev] = true;
+    }
+    if (*prefix_fused) {
+        static bool ride_attr_done[2][64] = {};
+        if (!ride_attr_done[exact][dev]) {
+            hipError_t e = exact ? hipFuncSetAttribute((const void*)k_march<T, C, S, A, true, false, true>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + extra_lds)
+                                 : hipFuncSetAttribute((const void*)k_march<T, C, S, A, false, false, true>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + extra_lds);
+            if (e != hipSuccess) return e;
+            ride_attr_done[exact][dev] = true;
+        }
+        if (exact)
+            hipLaunchKernelGGL((k_march<T, C, S, A, true, false, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc, chunk_rows);
+        else
+            hipLaunchKernelGGL((k_march<T, C, S, A, false, false, true>), grid, dim3(K::NT), K::LDS_BYTES + extra_lds, stream, g, t,
+                               fc, chunk_rows);
+        return hipGetLastError();
     }
     if (exact)
         hipLaunchKernelGGL((k_march<T, C, S, A, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc, chunk_rows);
@@ -684,10 +806,11 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g, cons
 }
 
 inline hipError_t march_launch(const lanczos_desc& d, const FrameGeom& g, const TapTables& t, const FastConsts& fc,
-                               hipStream_t stream) {
+                               hipStream_t stream, bool* prefix_fused) {
+    *prefix_fused = false;
 #define X(T, C, S, A)                                                                               \
     if (d.bytes_per_sample == (int)sizeof(T) && d.channels == C && d.scale_n == S && d.a == A)      \
-        return march_launch_t<T, C, S, A>(d, g, t, fc, stream);
+        return march_launch_t<T, C, S, A>(d, g, t, fc, stream, prefix_fused);
     LZ_FAST_CONFIGS(X)
 #undef X
     return hipErrorNotSupported;
