@@ -220,7 +220,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     // instead of being held in registers across the other phases: the kernel sits on its 72-VGPR budget.)
     auto issue_loads = [&](int tick) {
         int t1 = tid;
-        if (RIDE) asm volatile("" : "+v"(t1));
+        if (RIDE || STAMP) asm volatile("" : "+v"(t1));
 #pragma unroll
         for (int it = 0; it < K::LOAD_IT; it++) {
             const int idx = t1 + it * K::NT;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
         const uint8_t* tin = smem + (tick & 1) * K::TIN_BYTES;
         const int h0 = hb + tick * K::MS;           // first H row of the tick
         int t3 = tid;
-        if (RIDE) asm volatile("" : "+v"(t3));
+        if (RIDE || STAMP) asm volatile("" : "+v"(t3));
         const int row = t3 / K::UPR, u = t3 % K::UPR;
         const bool unit_ok = t3 < K::NU && h0 + row <= h_last && !(g.debug_skip & 1);
         uint32_t im = 0;      // undecided integer-phase samples: bit (8*e*SB + i) <-> own input sample i*VEC + e
@@ -490,7 +490,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
 
     auto vpass = [&](int tick) {
         int t2 = tid;
-        if (RIDE) asm volatile("" : "+v"(t2));
+        if (RIDE || STAMP) asm volatile("" : "+v"(t2));
         const int grp = K::NGRP == 1 ? (t2 < K::NVT ? 0 : 1) : grp_w;
         const int col = t2 - grp * K::NVT;
         const unsigned col_b = (unsigned)(tx * F::TWB_OUT + col * 4);
