@@ -21,7 +21,16 @@
 //   VPASS     tick t: one dword column per thread, 2a-row register window over the ring; integer-phase rows
 //             are dword copies, the others 2a fmaf + one v_cvt_pk_u8_f32 per sample; buffer stores with the
 //             row offset in the scalar operand
-// ~40 KiB of LDS per workgroup: 3-4 workgroups (18-24 waves) per CU.
+// ~40 KiB of LDS per workgroup: 4 workgroups (24 waves) per CU at 72 VGPRs / 96 SGPRs.
+//
+// Around the tick loop (all measured, profiles/README.md):
+//   * the grid is 1-D and re-numbered so that the ids one XCD receives are consecutive: neighbouring strips share an L2
+//     and every input line is fetched from HBM once;
+//   * the output stores are non-temporal (the output must not evict the input rows neighbours re-read);
+//   * the phase weights live in VGPRs (an SGPR source puts a VALU op in gfx950's slow issue class), the exact chain's
+//     double weights in memory (as kernel arguments they cost 24 SGPRs and spilled);
+//   * RIDE variant (small batches): the in-place prefix rows (k_prefix) are extra workgroups at the end of this grid;
+//   * EXACT variant: the V pass keeps its exactness test; undecided rows are redone in f64 after the row loop.
 #pragma once
 #include <cstdio>
 #include <cstdlib>
