@@ -366,3 +366,28 @@ def test_frame_strides_and_kernel_families(ctx, pad_in, pad_out):
             g = got[f * out_stride:f * out_stride + out_fb].reshape(d.out_h, d.out_w, c)
             _cmp(g, want[f], mode, f"frame {f} pads {pad_in}/{pad_out}")
             assert np.all(got[f * out_stride + out_fb:(f + 1) * out_stride] == 0x5A), "padding between frames was written"
+
+
+def test_prefix_rows_ride_or_run_separately(ctx):
+    """The in-place prefix rows (output rows < K) either ride on the marching launch (small batches) or run as the
+    separate k_prefix launch (more than about one prefix workgroup per CU): both must give the reference's rows."""
+    import torch
+    w, h, c, sn, a = 208, 96, 3, 2, 3
+    img = P.gradient_noise(h, w, c, seed=5)
+    cfg = O.cfg(w, h, w * sn, h * sn, c, a, sn, 1)
+    want = O.expected_hwc_u8(cfg, img)
+    d = L.make_desc(w, h, c, sn, 1, a, 1, L.MODE_EXACT)
+    k = L._lib().lanczos_inplace_rows(__import__("ctypes").byref(d))
+    assert k >= 1
+    for frames in (1, 7, 96):   # 96 frames x 4 prefix workgroups each > 256 CUs: the separate launch
+        x = torch.from_numpy(np.repeat(img[None], frames, axis=0)).cuda()
+        y = torch.zeros((frames, h * sn, w * sn, c), dtype=torch.uint8, device="cuda")
+        for mode in (L.MODE_EXACT, L.MODE_LSB1):
+            d.mode = mode
+            y.zero_()
+            ctx.resample_device(d, x.data_ptr(), y.data_ptr(), frames, 0, 0, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = y.cpu().numpy()
+            for f in (0, frames // 2, frames - 1):
+                _cmp(got[f], want, mode, f"{frames} frames, frame {f}")
+                assert np.array_equal(got[f][:k], want[:k]) or mode == L.MODE_LSB1
