@@ -8,7 +8,11 @@
  *                                             lanczos.cpp:86-98 (called at full_TB.h:140); results are
  *                                             those of the software model lanczos_expected(),
  *                                             full_TB.h:79-96, on the stb interleaved layout of
- *                                             full_TB.h:107 (R | G<<8 | B<<16, worker.cpp:35-43)
+ *                                             full_TB.h:107 (R | G<<8 | B<<16, worker.cpp:35-43):
+ *                                             bit-identical with LANCZOS_MODE_EXACT (what lanczos_u8 and
+ *                                             hls_compat.hpp's lanczos() use), within +-1 LSB per sample
+ *                                             with LANCZOS_MODE_LSB1 (what lanczos_desc_init sets: the
+ *                                             faster default of the batch / device entry points)
  *   lanczos_resample_device                <- the same, for callers that already hold device memory
  *                                             (batches of frames, row strips of one frame)
  *   lanczos_kernel / lanczos_kernel_idx    <- double lanczos_kernel(double)      full_TB.h:51-53 and
@@ -120,7 +124,8 @@ int lanczos_interleaved_to_planar_device(lanczos_ctx* ctx, const void* d_interle
  * Whole frames only; the interleaved scratch frames live in the context (one stream at a time per context). */
 int lanczos_resample_planar_device(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in_planar, void* d_out_planar,
                                    int frames, void* stream);
-/* The reference's call shape: sizes as plain ints, RGB8 in/out, scale = out_w/in_w reduced. */
+/* The reference's call shape: sizes as plain ints, RGB8 in/out, scale = out_w/in_w reduced.
+ * Always LANCZOS_MODE_EXACT: the bytes are those of lanczos_expected() (full_TB.h:79-96). */
 int lanczos_u8(lanczos_ctx* ctx, const uint8_t* in, int in_w, int in_h, int channels,
                uint8_t* out, int out_w, int out_h, int a);
 

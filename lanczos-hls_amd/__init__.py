@@ -235,6 +235,11 @@ class Context:
     def resample_strip(self, strip_in, desc):
         """One row strip (desc.out_row0/out_rows set); strip_in holds the rows strip_input_rows() names."""
         strip_in = np.ascontiguousarray(strip_in)
+        _, need = strip_input_rows(desc, desc.out_row0, desc.out_rows)
+        if (strip_in.ndim != 3 or strip_in.shape[0] != need or strip_in.shape[1] != desc.in_w
+                or strip_in.shape[2] != desc.channels or strip_in.dtype.itemsize != desc.bytes_per_sample):
+            raise LanczosError(ERR_BAD_ARG, f"resample_strip: expected [{need}][{desc.in_w}][{desc.channels}] samples of "
+                                            f"{desc.bytes_per_sample} byte(s), got {strip_in.shape} {strip_in.dtype}")
         out = np.empty((desc.out_rows, desc.out_w, desc.channels), dtype=strip_in.dtype)
         _check(_lib().lanczos_resample_host(self._h, ctypes.byref(desc), strip_in.ctypes.data,
                                             out.ctypes.data, 1), "lanczos_resample_host")

@@ -370,7 +370,9 @@ int lanczos_timing_enable(lanczos_ctx* ctx, int on) {
 }
 
 static int timing_flush(lanczos_ctx* ctx) {
-    for (int i = 0; i + 2 < ctx->ev_used; i += 3) {
+    const int used = ctx->ev_used;
+    ctx->ev_used = 0;  // whatever happens below, the next call starts from a clean slate
+    for (int i = 0; i + 2 < used; i += 3) {
         float a = 0, b = 0;
         LZ_HIP(ctx, hipEventSynchronize(ctx->ev[i + 2]));
         LZ_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[i], ctx->ev[i + 1]));
@@ -379,7 +381,6 @@ static int timing_flush(lanczos_ctx* ctx) {
         ctx->prefix_ms += b;
         ctx->launches++;
     }
-    ctx->ev_used = 0;
     return LANCZOS_OK;
 }
 
@@ -406,12 +407,10 @@ int lanczos_force_kernel(lanczos_ctx* ctx, int family) {
     return LANCZOS_OK;
 }
 
-int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in, void* d_out, int frames,
-                            size_t in_frame_stride, size_t out_frame_stride, void* stream_v) {
-    if (!ctx || !d_in || !d_out || frames <= 0) return LANCZOS_ERR_BAD_ARG;
-    int rc = lz::validate(d);
-    if (rc != LANCZOS_OK) return rc;
-    std::lock_guard<std::mutex> lock(ctx->mu);
+// the resample proper; ctx->mu is held by the caller
+static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in, void* d_out, int frames,
+                                  size_t in_frame_stride, size_t out_frame_stride, void* stream_v) {
+    int rc;
     LZ_HIP(ctx, hipSetDevice(ctx->device));
     Plan* p = nullptr;
     rc = get_plan(ctx, d, &p);
@@ -464,6 +463,13 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
         }
     }
 
+    bool prefix_fused = false;
+    bool use_fast = p->fast_ok && ctx->force != LANCZOS_KERNEL_GENERIC &&
+                    lz::fast_supports(*d, g);
+    if (ctx->force == LANCZOS_KERNEL_FAST && !use_fast) return LANCZOS_ERR_UNSUPPORTED;
+
+    // Events are reserved only once nothing but a HIP failure can stop the call; a triple is committed (ev_used += 3)
+    // after all three records succeeded, so timing_flush never meets an unrecorded event.
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     if (ctx->timing) {
         if (ctx->ev_used + 3 > 3 * 4096) {
@@ -478,14 +484,8 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
         ev0 = ctx->ev[ctx->ev_used];
         ev1 = ctx->ev[ctx->ev_used + 1];
         ev2 = ctx->ev[ctx->ev_used + 2];
-        ctx->ev_used += 3;
         LZ_HIP(ctx, hipEventRecord(ev0, stream));
     }
-
-    bool prefix_fused = false;
-    bool use_fast = p->fast_ok && ctx->force != LANCZOS_KERNEL_GENERIC &&
-                    lz::fast_supports(*d, g);
-    if (ctx->force == LANCZOS_KERNEL_FAST && !use_fast) return LANCZOS_ERR_UNSUPPORTED;
     if (use_fast) {
         // LANCZOS_TILE_KERNEL=1 selects the older tile-per-workgroup kernel (kept for A/B measurements)
         static const bool use_tile = getenv("LANCZOS_TILE_KERNEL") && atoi(getenv("LANCZOS_TILE_KERNEL")) != 0;
@@ -538,8 +538,20 @@ int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void*
 #undef LZ_PREFIX
         LZ_HIP(ctx, hipGetLastError());
     }
-    if (ev2) LZ_HIP(ctx, hipEventRecord(ev2, stream));
+    if (ev2) {
+        LZ_HIP(ctx, hipEventRecord(ev2, stream));
+        ctx->ev_used += 3;
+    }
     return LANCZOS_OK;
+}
+
+int lanczos_resample_device(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in, void* d_out, int frames,
+                            size_t in_frame_stride, size_t out_frame_stride, void* stream_v) {
+    if (!ctx || !d_in || !d_out || frames <= 0) return LANCZOS_ERR_BAD_ARG;
+    int rc = lz::validate(d);
+    if (rc != LANCZOS_OK) return rc;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return resample_device_locked(ctx, d, d_in, d_out, frames, in_frame_stride, out_frame_stride, stream_v);
 }
 
 int lanczos_host_alloc(void** p, size_t bytes) {
@@ -561,74 +573,74 @@ int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* i
     if (!ctx || !in || !out || frames <= 0) return LANCZOS_ERR_BAD_ARG;
     int rc = lz::validate(d);
     if (rc != LANCZOS_OK) return rc;
-    size_t in_frame, out_frame;
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        LZ_HIP(ctx, hipSetDevice(ctx->device));
-        Plan* p = nullptr;
-        rc = get_plan(ctx, d, &p);
-        if (rc != LANCZOS_OK) return rc;
-        int row0, rows, in_row0, in_rows;
-        whole_or_strip(d, &row0, &rows);
-        strip_input_rows(p->V, d->a, d->in_h, row0, rows, p->prefix, &in_row0, &in_rows);
-        in_frame = (size_t)d->in_w * d->channels * d->bytes_per_sample * in_rows;
-        out_frame = (size_t)d->out_w * d->channels * d->bytes_per_sample * rows;
-        const size_t in_bytes = in_frame * frames, out_bytes = out_frame * frames;
-        if (ctx->stage_in_bytes < in_bytes) {
-            if (ctx->stage_in) (void)hipFree(ctx->stage_in);
-            ctx->stage_in = nullptr;
-            ctx->stage_in_bytes = 0;
-            LZ_HIP(ctx, hipMalloc(&ctx->stage_in, in_bytes));
-            ctx->stage_in_bytes = in_bytes;
-        }
-        if (ctx->stage_out_bytes < out_bytes) {
-            if (ctx->stage_out) (void)hipFree(ctx->stage_out);
-            ctx->stage_out = nullptr;
-            ctx->stage_out_bytes = 0;
-            LZ_HIP(ctx, hipMalloc(&ctx->stage_out, out_bytes));
-            ctx->stage_out_bytes = out_bytes;
-        }
-        if (!ctx->copy_in) LZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
-        if (!ctx->copy_out) LZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
+    // The staging buffers, the two copy streams and the pipeline events belong to the context: the lock is held
+    // for the whole call (calls on one context are serialised; use one context per host thread to overlap them).
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    LZ_HIP(ctx, hipSetDevice(ctx->device));
+    Plan* p = nullptr;
+    rc = get_plan(ctx, d, &p);
+    if (rc != LANCZOS_OK) return rc;
+    int row0, rows, in_row0, in_rows;
+    whole_or_strip(d, &row0, &rows);
+    strip_input_rows(p->V, d->a, d->in_h, row0, rows, p->prefix, &in_row0, &in_rows);
+    const size_t in_frame = (size_t)d->in_w * d->channels * d->bytes_per_sample * in_rows;
+    const size_t out_frame = (size_t)d->out_w * d->channels * d->bytes_per_sample * rows;
+    const size_t in_bytes = in_frame * frames, out_bytes = out_frame * frames;
+    if (ctx->stage_in_bytes < in_bytes) {
+        if (ctx->stage_in) (void)hipFree(ctx->stage_in);
+        ctx->stage_in = nullptr;
+        ctx->stage_in_bytes = 0;
+        LZ_HIP(ctx, hipMalloc(&ctx->stage_in, in_bytes));
+        ctx->stage_in_bytes = in_bytes;
     }
+    if (ctx->stage_out_bytes < out_bytes) {
+        if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+        ctx->stage_out = nullptr;
+        ctx->stage_out_bytes = 0;
+        LZ_HIP(ctx, hipMalloc(&ctx->stage_out, out_bytes));
+        ctx->stage_out_bytes = out_bytes;
+    }
+    if (!ctx->copy_in) LZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
+    if (!ctx->copy_out) LZ_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
     // groups of at most 4 frames, at most 64 groups in flight per call
     int group = frames >= 8 ? 4 : (frames >= 2 ? (frames + 1) / 2 : 1);
     if ((frames + group - 1) / group > 64) group = (frames + 63) / 64;
     const int ngroups = (frames + group - 1) / group;
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        while ((int)ctx->pipe_ev.size() < 2 * ngroups) {
-            hipEvent_t e;
-            LZ_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->pipe_ev.push_back(e);
-        }
+    while ((int)ctx->pipe_ev.size() < 2 * ngroups) {
+        hipEvent_t e;
+        LZ_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->pipe_ev.push_back(e);
     }
-    for (int gi = 0; gi < ngroups; gi++) {
-        const int f0 = gi * group, nf = (f0 + group <= frames) ? group : frames - f0;
-        const uint8_t* hin = (const uint8_t*)in + (size_t)f0 * in_frame;
-        uint8_t* din = (uint8_t*)ctx->stage_in + (size_t)f0 * in_frame;
-        uint8_t* dout = (uint8_t*)ctx->stage_out + (size_t)f0 * out_frame;
-        uint8_t* hout = (uint8_t*)out + (size_t)f0 * out_frame;
-        {
-            std::lock_guard<std::mutex> lock(ctx->mu);
+    // One failing step must not leave copies in flight on the caller's buffers: whatever the outcome, all three
+    // streams are drained before the call returns.
+    auto pipeline = [&]() -> int {
+        for (int gi = 0; gi < ngroups; gi++) {
+            const int f0 = gi * group, nf = (f0 + group <= frames) ? group : frames - f0;
+            const uint8_t* hin = (const uint8_t*)in + (size_t)f0 * in_frame;
+            uint8_t* din = (uint8_t*)ctx->stage_in + (size_t)f0 * in_frame;
+            uint8_t* dout = (uint8_t*)ctx->stage_out + (size_t)f0 * out_frame;
+            uint8_t* hout = (uint8_t*)out + (size_t)f0 * out_frame;
             LZ_HIP(ctx, hipMemcpyAsync(din, hin, in_frame * nf, hipMemcpyHostToDevice, ctx->copy_in));
             LZ_HIP(ctx, hipEventRecord(ctx->pipe_ev[2 * gi], ctx->copy_in));
             LZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_ev[2 * gi], 0));
-        }
-        rc = lanczos_resample_device(ctx, d, din, dout, nf, 0, 0, ctx->stream);
-        if (rc != LANCZOS_OK) return rc;
-        {
-            std::lock_guard<std::mutex> lock(ctx->mu);
+            const int rc2 = resample_device_locked(ctx, d, din, dout, nf, 0, 0, ctx->stream);
+            if (rc2 != LANCZOS_OK) return rc2;
             LZ_HIP(ctx, hipEventRecord(ctx->pipe_ev[2 * gi + 1], ctx->stream));
             LZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_out, ctx->pipe_ev[2 * gi + 1], 0));
             LZ_HIP(ctx, hipMemcpyAsync(hout, dout, out_frame * nf, hipMemcpyDeviceToHost, ctx->copy_out));
         }
-    }
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        LZ_HIP(ctx, hipStreamSynchronize(ctx->copy_out));
-        LZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+        return LANCZOS_OK;
+    };
+    rc = pipeline();
+    const hipError_t e_in = hipStreamSynchronize(ctx->copy_in);
+    const hipError_t e_k = hipStreamSynchronize(ctx->stream);
+    const hipError_t e_out = hipStreamSynchronize(ctx->copy_out);
+    if (rc != LANCZOS_OK) return rc;
+    for (hipError_t e : {e_in, e_k, e_out})
+        if (e != hipSuccess) {
+            ctx->last_hip = (int)e;
+            return LANCZOS_ERR_HIP;
+        }
     return LANCZOS_OK;
 }
 
@@ -703,6 +715,9 @@ int lanczos_u8(lanczos_ctx* ctx, const uint8_t* in, int in_w, int in_h, int chan
     int rc = lanczos_desc_init(&d, in_w, in_h, channels, 1, out_w, in_w, a);
     if (rc != LANCZOS_OK) return rc;
     if (d.out_w != out_w || d.out_h != out_h) return LANCZOS_ERR_BAD_ARG;  // full_TB.h:115-118
+    // the reference-shaped single-frame entry point returns lanczos_expected()'s bytes, bit for bit; the batch and
+    // device entry points default to LANCZOS_MODE_LSB1 (lanczos_desc_init)
+    d.mode = LANCZOS_MODE_EXACT;
     return lanczos_resample_host(ctx, &d, in, out, 1);
 }
 

@@ -24,6 +24,7 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #include "lanczos_kernels_common.hpp"
 #include "lanczos_taps.hpp"
@@ -479,6 +480,14 @@ __global__ __launch_bounds__((FastCfg<T, C, S, A>::NT)) void k_fast(FrameGeom g,
 }
 
 // ---------------------------------------------------------------------------------- host side
+// The launch helpers cache per-device facts (occupancy answers, "dynamic LDS attribute set") in function-local statics.
+// Contexts on different host threads share them, so every access happens under this one process-wide mutex
+// (uncontended: tens of nanoseconds per launch).
+inline std::mutex& launch_cache_mutex() {
+    static std::mutex m;
+    return m;
+}
+
 inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTaps& V, FastConsts* fc) {
     const int S = d.scale_n, a = d.a, taps = 2 * a;
     if (d.scale_d != 1 || S < 2 || S > kFastMaxS) return false;
@@ -559,6 +568,7 @@ inline hipError_t fast_launch_t(const lanczos_desc& d, const FrameGeom& g, const
     const int ty0 = g.out_row0 / K::TH;
     const int ty1 = (g.out_row0 + g.out_rows - 1) / K::TH;
     dim3 grid(tiles_x * (ty1 - ty0 + 1), g.frames);
+    std::lock_guard<std::mutex> cache_lock(launch_cache_mutex());
     static bool attr_done[2][64] = {};
     const bool exact = d.mode == LANCZOS_MODE_EXACT;
     int dev = 0;

@@ -732,6 +732,7 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     const int y_hi = g.out_row0 + g.out_rows;
     if (y_lo >= y_hi) return hipSuccess;
     const int m_rows = (y_hi - 1) / S - y_lo / S + 1;
+    std::lock_guard<std::mutex> cache_lock(launch_cache_mutex());  // slots[], attr_done[], ride_attr_done[] below
     static int slots[2][64] = {};
     const bool exact_ = d.mode == LANCZOS_MODE_EXACT;
     int dev_ = 0;

@@ -6,6 +6,9 @@
 #include <string.h>
 #include <zlib.h>
 
+/* largest width / height accepted from a file header (stb's STBI_MAX_DIMENSIONS is 1 << 24) */
+#define LZ_IMAGE_MAX_DIM (1 << 24)
+
 static const char* g_err = "";
 const char* lz_image_last_error(void) { return g_err; }
 void lz_image_free(void* p) { free(p); }
@@ -119,7 +122,7 @@ static uint8_t* load_png(const uint8_t* buf, size_t n, int* w, int* h, int* ch) 
         }
         pos += 12 + len;
     }
-    if (W <= 0 || H <= 0 || depth != 8 || interlace != 0 || !z) {
+    if (W <= 0 || H <= 0 || W > LZ_IMAGE_MAX_DIM || H > LZ_IMAGE_MAX_DIM || depth != 8 || interlace != 0 || !z) {
         g_err = "unsupported PNG (need 8-bit, non-interlaced)";
         free(z);
         return NULL;
@@ -194,6 +197,10 @@ static uint8_t* load_pnm(const uint8_t* buf, size_t n, int* w, int* h, int* ch) 
         }
         int v = 0, any = 0;
         while (pos < n && buf[pos] >= '0' && buf[pos] <= '9') {
+            if (v > LZ_IMAGE_MAX_DIM) { /* header fields are bounded: no signed overflow on hostile input */
+                g_err = "PNM header value too large";
+                return NULL;
+            }
             v = v * 10 + (buf[pos++] - '0');
             any = 1;
         }
@@ -202,7 +209,8 @@ static uint8_t* load_pnm(const uint8_t* buf, size_t n, int* w, int* h, int* ch) 
     }
     pos++; /* single whitespace after maxval */
     int c = buf[1] == '6' ? 3 : 1;
-    if (got < 3 || vals[2] != 255 || pos + (size_t)vals[0] * vals[1] * c > n) {
+    if (got < 3 || vals[0] <= 0 || vals[1] <= 0 || vals[0] > LZ_IMAGE_MAX_DIM || vals[1] > LZ_IMAGE_MAX_DIM ||
+        vals[2] != 255 || pos > n || (size_t)vals[0] * vals[1] * c > n - pos) {
         g_err = "unsupported PNM (need maxval 255)";
         return NULL;
     }

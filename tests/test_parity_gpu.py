@@ -197,8 +197,8 @@ def test_u16_matches_the_templated_checker(ctx):
 
 def test_reference_call_shape_and_errors(ctx):
     img = P.gradient_noise(48, 64, 3)
-    got = ctx.u8(img, 128, 96, 3)
-    _cmp(got, _oracle(img, 2, 1, 3), L.MODE_LSB1, "lanczos_u8")
+    got = ctx.u8(img, 128, 96, 3)       # the reference-shaped entry point is always bit-exact
+    _cmp(got, _oracle(img, 2, 1, 3), L.MODE_EXACT, "lanczos_u8")
     with pytest.raises(L.LanczosError) as e:
         ctx.u8(img, 130, 96, 3)          # wrong output size: full_TB.h:115-118
     assert e.value.code == L.ERR_BAD_ARG
@@ -237,6 +237,84 @@ def test_full_size_config2_against_oracle(ctx, pattern):
     batch = np.stack([img, P.noise(1080, 1920, 3, seed=3), img[::-1].copy()])
     got = ctx.resample(batch, 2, 1, 3, L.MODE_LSB1)
     _cmp(got[0], want, L.MODE_LSB1, f"full-size {pattern} in a batch")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 at FULL size: 3840x2160x4 uint16 -> 7680x4320, a = 4.  PARITY UNPINNED BY THE REFERENCE (it has no
+# 16-bit path, full_TB.h:18,30): the checker is the restatement templated on the sample type (clamp 65535).
+
+C5 = (3840, 2160, 4, 2, 1, 4)
+
+
+def _c5_frame():
+    w, h, c = C5[:3]
+    return O.lcg_u16(h * w * c, 12345).reshape(h, w, c)
+
+
+def test_full_size_config5_digest(ctx):
+    """EXACT mode at full size against the committed FNV-1a-64 of the u16 restatement's output
+    (tests/golden/make_golden_u16.py) -- no CPU resample on the box."""
+    with open(os.path.join(GOLD, "kat_digests_u16.json")) as f:
+        kat = json.load(f)["digests"]
+    w, h, c, sn, sd, a = C5
+    got = ctx.resample(_c5_frame(), sn, sd, a, L.MODE_EXACT)
+    assert got.shape == (h * 2, w * 2, c) and got.dtype == np.uint16
+    assert ctx.last_kernel() == L.KERNEL_FAST
+    assert f"{O.fnv1a64(got):016x}" == kat["3840x2160_7680x4320_2-1_a4_c4"]
+    for shape in ("480x270_960x540_2-1_a4_c4", "320x180_640x360_2-1_a3_c3", "150x100_200x133_4-3_a3_c3"):
+        iw, ih, ow, oh, sn2, sd2, a2, c2 = _parse(shape)
+        img = O.lcg_u16(ih * iw * c2, 12345).reshape(ih, iw, c2)
+        got = ctx.resample(img, sn2, sd2, a2, L.MODE_EXACT)
+        assert f"{O.fnv1a64(got):016x}" == kat[shape], shape
+
+
+def test_full_size_config5_against_oracle(ctx):
+    """Both parity modes at full size, every sample against the threaded checker; gradient-like u16 content
+    (the LCG noise frame is covered by the digest test)."""
+    w, h, c, sn, sd, a = C5
+    y, x = np.mgrid[0:h, 0:w]
+    base = ((x * 65535 // w + y * 65535 // h) // 2).astype(np.int64)
+    nz = (O.lcg_u16(h * w * c, 99).reshape(h, w, c) >> 6).astype(np.int64)
+    img = np.clip(base[..., None] + nz, 0, 65535).astype(np.uint16)
+    want = _oracle(img, sn, sd, a, threads=min(os.cpu_count() or 8, 64))
+    for mode in (L.MODE_EXACT, L.MODE_LSB1):
+        got = ctx.resample(img, sn, sd, a, mode)
+        _cmp(got, want, mode, "full-size config 5")
+        assert ctx.last_kernel() == L.KERNEL_FAST
+
+
+def test_full_size_config5_as_8_row_strips(ctx):
+    """Config 5's tile sharding on one GPU: the frame as 8 output row strips of 540 rows, each from its input rows +
+    halo (lanczos_strip_input_rows), through the DEVICE path each rank of bench.py --shard strips uses; the strips
+    reassemble to the whole-frame result, bit for bit, in both modes."""
+    import torch
+    w, h, c, sn, sd, a = C5
+    img = _c5_frame()
+    x = torch.from_numpy(img.view(np.int16)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    for mode in (L.MODE_EXACT, L.MODE_LSB1):
+        full = L.make_desc(w, h, c, sn, sd, a, 2, mode)
+        y_whole = torch.zeros((full.out_h, full.out_w, c), dtype=torch.int16, device="cuda")
+        ctx.resample_device(full, x.data_ptr(), y_whole.data_ptr(), 1, 0, 0, stream)
+        y_strips = torch.zeros_like(y_whole)
+        for i in range(8):
+            d = L.make_desc(w, h, c, sn, sd, a, 2, mode, out_row0=540 * i, out_rows=540)
+            r0, n = L.strip_input_rows(d, d.out_row0, d.out_rows)
+            assert r0 == max(0, 270 * i - 3) and r0 + n - 1 == min(h - 1, 270 * i + 269 + 4)
+            xin = x[r0:r0 + n].contiguous()
+            yout = torch.zeros((540, full.out_w, c), dtype=torch.int16, device="cuda")
+            ctx.resample_device(d, xin.data_ptr(), yout.data_ptr(), 1, 0, 0, stream)
+            y_strips[540 * i:540 * (i + 1)] = yout
+        torch.cuda.synchronize()
+        assert torch.equal(y_strips, y_whole), f"mode {mode}: strips differ from the whole frame"
+
+
+def test_full_size_config3_against_oracle(ctx):
+    """BASELINE config 3 (1280x720 -> 3840x2160, 3x) at full size, gradient content, both modes."""
+    img = P.gradient_noise(720, 1280, 3)
+    want = _oracle(img, 3, 1, 3, threads=32)
+    for mode in (L.MODE_LSB1, L.MODE_EXACT):
+        _cmp(ctx.resample(img, 3, 1, 3, mode), want, mode, "full-size config 3")
 
 
 def test_device_path_is_ordered_behind_the_default_stream(ctx):
