@@ -62,6 +62,9 @@ struct lanczos_ctx {
     double main_ms = 0, prefix_ms = 0;
     void* stamp_buf = nullptr;
     hipStream_t copy_in = nullptr, copy_out = nullptr;  // lanczos_resample_host pipeline
+    // the in-place prefix rows of integer scales run on a side stream BESIDE the marching kernel (k_prefix_reg)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> pipe_ev;
     // interleaved scratch frames of lanczos_resample_planar_device
     void* planar_in = nullptr;
@@ -352,6 +355,9 @@ int lanczos_destroy(lanczos_ctx* ctx) {
     }
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
     if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
     if (ctx->planar_in) (void)hipFree(ctx->planar_in);
@@ -405,6 +411,42 @@ int lanczos_force_kernel(lanczos_ctx* ctx, int family) {
     if (!ctx || family < LANCZOS_KERNEL_NONE || family > LANCZOS_KERNEL_FAST) return LANCZOS_ERR_BAD_ARG;
     ctx->force = family;
     return LANCZOS_OK;
+}
+
+// In-place prefix rows of an integer scale on the context's side stream (k_prefix_reg).  hipErrorNotSupported: no
+// instance for this (sample type, scale, a) -- the caller falls back to the serial k_prefix.
+static hipError_t launch_prefix_side(lanczos_ctx* ctx, const lanczos_desc* d, const lz::FrameGeom& g, const Plan* p,
+                                     hipStream_t stream, bool same_stream) {
+#define LZ_PREFIX_REG_CONFIGS(X) X(uint8_t, 2, 3) X(uint8_t, 3, 3) X(uint8_t, 2, 2) X(uint8_t, 2, 4) X(uint16_t, 2, 4) X(uint16_t, 2, 3)
+    bool have = false;
+#define X(T, S, A)                                                                                                    \
+    if (d->bytes_per_sample == (int)sizeof(T) && d->scale_n == S && d->a == A && p->prefix.K == lz::prefix_K(S, A) && \
+        p->prefix.M == lz::prefix_M(S, A) && p->prefix.M2 == lz::prefix_M2(S, A))                                    \
+        have = true;
+    LZ_PREFIX_REG_CONFIGS(X)
+#undef X
+    if (!have) return hipErrorNotSupported;
+    hipError_t e;
+    hipStream_t ks = stream;
+    if (!same_stream) {
+        if (!ctx->side) {
+            if ((e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        if ((e = hipEventRecord(ctx->ev_fork, stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0)) != hipSuccess) return e;
+        ks = ctx->side;
+    }
+    const int samples_w = d->out_w * d->channels;
+    dim3 grid((samples_w + 127) / 128, g.frames);
+#define X(T, S, A)                                                                                  \
+    if (d->bytes_per_sample == (int)sizeof(T) && d->scale_n == S && d->a == A)                      \
+        hipLaunchKernelGGL((lz::k_prefix_reg<T, S, A>), grid, dim3(128), 0, ks, g, p->dev);
+    LZ_PREFIX_REG_CONFIGS(X)
+#undef X
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return same_stream ? hipSuccess : hipEventRecord(ctx->ev_join, ctx->side);
 }
 
 // the resample proper; ctx->mu is held by the caller
@@ -486,9 +528,12 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
         ev2 = ctx->ev[ctx->ev_used + 2];
         LZ_HIP(ctx, hipEventRecord(ev0, stream));
     }
+    bool prefix_side = false;  // the prefix rows were launched on the side stream, before the main kernel
+    bool prefix_same = false;  // ... or on this stream, in front of the main kernel (register-only kernel)
     if (use_fast) {
         // LANCZOS_TILE_KERNEL=1 selects the older tile-per-workgroup kernel (kept for A/B measurements)
         static const bool use_tile = getenv("LANCZOS_TILE_KERNEL") && atoi(getenv("LANCZOS_TILE_KERNEL")) != 0;
+        static const bool serial_prefix = getenv("LANCZOS_SERIAL_PREFIX") && atoi(getenv("LANCZOS_SERIAL_PREFIX")) != 0;
         hipError_t e;
         if (use_tile || !lz::march_supports(g)) {
             e = lz::fast_launch(*d, g, p->dev, p->fast, stream);
@@ -498,8 +543,26 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
                 gm.prefix_K = p->prefix.K;
                 gm.prefix_M = p->prefix.M;
                 gm.prefix_M2 = p->prefix.M2;
+                e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &prefix_fused, /*query_only=*/true);
+                if (e == hipSuccess && !prefix_fused) {
+                    // Large batch: the prefix rows neither ride nor wait -- the register-only kernel goes out FIRST, on the
+                    // side stream, and shares the CUs with the marching kernel's first microseconds (it needs no LDS, the
+                    // marching workgroups need all of it).  fork: side waits for everything queued on `stream` so far;
+                    // join (below): `stream` waits for the side kernel.
+                    gm.prefix_K = gm.prefix_M = gm.prefix_M2 = 0;
+                    static const int prefix_mode = getenv("LANCZOS_PREFIX_MODE") ? atoi(getenv("LANCZOS_PREFIX_MODE")) : 1;  // 1: same stream, in front (measured best); 2: side stream
+                    if (!serial_prefix && d->scale_d == 1 && d->in_h >= p->prefix.M2) {
+                        hipError_t pe = launch_prefix_side(ctx, d, g, p, stream, prefix_mode != 2);
+                        if (pe == hipSuccess) {
+                            prefix_side = prefix_mode == 2;
+                            prefix_same = prefix_mode != 2;
+                        } else if (pe != hipErrorNotSupported) e = pe;
+                    }
+                }
+            } else {
+                e = hipSuccess;
             }
-            e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &prefix_fused);
+            if (e == hipSuccess) e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &prefix_fused);
         }
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
@@ -520,7 +583,8 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
     }
     if (ev1) LZ_HIP(ctx, hipEventRecord(ev1, stream));
 
-    if (has_prefix && !prefix_fused) {
+    if (prefix_side) LZ_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));  // join
+    if (has_prefix && !prefix_fused && !prefix_side && !prefix_same) {
         const int samples_w = d->out_w * d->channels;
         dim3 grid((samples_w + 127) / 128, frames);
 #define LZ_PREFIX(T, TAPS)                                                                                       \

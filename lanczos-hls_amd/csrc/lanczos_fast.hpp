@@ -42,6 +42,9 @@ struct FastConsts {
     float bias;                     // eps: f32-chain error bound, added to every sum
     float vbias_rne;                // eps - 0.5: bias under which the RNE byte convert is floor(sum + eps)
     float near2;                    // 2*eps: fract(sum+eps) below this = undecided
+    // the same three for the PAIRED chain of the marching kernel (S = 2: symmetric half-phase weights, 3 exact pair sums +
+    // 3 fmafs): eps_p < eps.  Equal to the plain ones when the weights are not symmetric (never used then).
+    float bias_p, vbias_rne_p, near2_p;
     int vlim;                       // integer-phase flip limit (0: the double chain never leaves v0)
     int skip_last;                  // 1: the last integer-phase tap (x - i = -a, ~1e-33) can never change the sum
     int tight;                      // 1: the only non-negligible negative integer-phase taps sit at +-2 pixels and
@@ -55,13 +58,15 @@ struct FastShape {
     static constexpr int NGRP = S == 2 ? 2 : 1;
 };
 
-template <typename T, int C_, int S_, int A_>
+// P_ / UPR_ = 0: the default unit geometry (the tile kernel's); the marching kernel's role-split configurations pass
+// wider units (P_ = 8 with UPR_ = 16: the same 128-pixel strip, half the units, 30 % fewer byte->float conversions)
+template <typename T, int C_, int S_, int A_, int P_ = 0, int UPR_ = 0>
 struct FastCfg {
     static constexpr int C = C_, S = S_, A = A_;
     static constexpr int SB = (int)sizeof(T);
     static constexpr int TAPS = 2 * A;
-    static constexpr int P = SB == 1 ? (C == 1 ? 8 : 4) : 2;  // input pixels per H unit
-    static constexpr int UPR = 32;                            // H units per tile row
+    static constexpr int P = P_ > 0 ? P_ : (SB == 1 ? (C == 1 ? 8 : 4) : 2);  // input pixels per H unit
+    static constexpr int UPR = UPR_ > 0 ? UPR_ : 32;                          // H units per tile row
     static constexpr int TWP_IN = P * UPR;
     static constexpr int TWP_OUT = TWP_IN * S;
     static constexpr int TWS_OUT = TWP_OUT * C;               // output samples per tile row
@@ -519,6 +524,25 @@ inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTap
     fc->bias = (float)eps;
     fc->vbias_rne = (float)eps - 0.5f;
     fc->near2 = (float)(2.0 * eps) * 1.0001f;
+    {   // paired chain (S = 2): acc = fma(w[k], v[k] + v[2a-1-k], acc), k = 0..a-1 (outside in); pair sums are exact
+        double eps_p = eps;
+        if (S == 2) {
+            const double* w = &ax->w[(size_t)(S * a + 1) * taps];
+            bool sym = true;
+            for (int k = 0; k < a; k++) sym = sym && (float)w[k] == (float)w[taps - 1 - k];
+            if (!sym) return false;  // cannot happen: L is even and x = m + 1/2 is exact
+            int order[kMaxTaps];
+            for (int k = 0; k < a; k++) order[k] = k;
+            // the exact-sum reference uses w[k] for v[k] and w[2a-1-k] for its partner: count that quantisation too
+            double wq_extra = 0;
+            for (int k = 0; k < a; k++) wq_extra += std::fabs((double)(float)w[k] - w[taps - 1 - k]) * maxv;
+            eps_p = f32_chain_error_bound_ordered(w, order, a, 2.0 * maxv) + 1.02 * wq_extra +
+                    4.0 * 2.220446049250313e-16 * (H.out_n > V.out_n ? H.out_n : V.out_n) * maxv * taps;
+        }
+        fc->bias_p = (float)eps_p;
+        fc->vbias_rne_p = (float)eps_p - 0.5f;
+        fc->near2_p = (float)(2.0 * eps_p) * 1.0001f;
+    }
     fc->vlim = integer_phase_flip_limit(fc->wi, a, (int)maxv);
     if (fc->vlim >= (d.bytes_per_sample == 1 ? 126 : 32766)) return false;  // SWAR test needs vlim < half range
     // Tight filter precondition.  Lower-bound chain (integer_phase_flip_limit): v0 can only be left through a

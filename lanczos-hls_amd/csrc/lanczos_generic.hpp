@@ -163,4 +163,90 @@ __global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K,
     }
 }
 
+// ---- the same rows for INTEGER scales, entirely in registers -------------------------------------------------------------
+// For an integer scale the tap rows are known at compile time (first = floor(y / S) - A + 1), so the recurrence unrolls
+// completely: hs[] / os[] are registers with static indices, no LDS at all.  That matters for more than speed: with no LDS
+// and < 80 VGPRs these workgroups fit on a CU BESIDE four resident marching workgroups (which own all 160 KiB of LDS), so
+// launched on a second stream just before the marching kernel they run inside its first microseconds instead of as a
+// serial 8.5 us kernel + 2.5 us gap behind it (profiles/README.md, round 2).
+constexpr int prefix_last_tap(int o, int S, int A) { return o / S + A; }
+constexpr int prefix_K(int S, int A) {
+    int k = 0;
+    for (int o = 0; o < 4 * A * S + 8; o++)
+        if (prefix_last_tap(o, S, A) > o) k = o + 1;
+    return k;
+}
+constexpr int prefix_M(int S, int A) {
+    int m = prefix_K(S, A);
+    for (int o = 0; o < prefix_K(S, A); o++)
+        if (prefix_last_tap(o, S, A) + 1 > m) m = prefix_last_tap(o, S, A) + 1;
+    return m;
+}
+constexpr int prefix_M2(int S, int A) {
+    int m2 = 0;
+    for (int o = 0; o < prefix_M(S, A); o++)
+        if (prefix_last_tap(o, S, A) + 1 > m2) m2 = prefix_last_tap(o, S, A) + 1;
+    return m2;
+}
+
+template <typename T, int S, int A>
+__global__ __launch_bounds__(128) void k_prefix_reg(FrameGeom g, TapTables t) {
+    constexpr int TAPS = 2 * A, K = prefix_K(S, A), M = prefix_M(S, A), M2 = prefix_M2(S, A);
+    const int C = g.channels;
+    const int samples_w = g.out_w * C;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int frame = blockIdx.y;
+    if (j >= samples_w) return;
+    const uint8_t* in_f = g.in + (size_t)frame * g.in_frame_stride;
+    uint8_t* out_f = g.out + (size_t)frame * g.out_frame_stride;
+    T hs[M2], os[M];
+    {   // horizontal pass of the rows the prefix reads (full_TB.h:55-65); the host guarantees in_h >= M2, in_row0 == 0
+        const int xx = j / C, c = j - xx * C;
+        const int first = t.h_first[xx];
+        int idx[TAPS];
+        double w[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) {
+            int i = first + k;
+            i = i < 0 ? 0 : (i > g.in_w - 1 ? g.in_w - 1 : i);  // weight is 0 there
+            idx[k] = i * C + c;
+            w[k] = t.h_w[(size_t)xx * TAPS + k];
+        }
+#pragma unroll
+        for (int r = 0; r < M2; r++) {
+            const T* row = (const T*)(in_f + (size_t)r * g.in_pitch);
+            T v[TAPS];
+#pragma unroll
+            for (int k = 0; k < TAPS; k++) v[k] = row[idx[k]];
+            double sum = 0;
+#pragma unroll
+            for (int k = 0; k < TAPS; k++) sum += (double)v[k] * w[k];
+            hs[r] = store_convert<T>(sum);
+        }
+    }
+    // full_TB.h:69-76, xx descending: a tap at row i > xx sees the value already written there.  Rows < 0 carry weight 0
+    // in the table; rows > in_h - 1 cannot occur (in_h >= M2).
+#pragma unroll
+    for (int xx = M - 1; xx >= 0; xx--) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int first = xx / S - A + 1;
+        const double* wv = t.v_w + (size_t)xx * TAPS;
+        double sum = 0;
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) {
+            const int i = first + k < 0 ? 0 : first + k;
+            const T v = i > xx ? os[i < M ? i : M - 1] : hs[i < M2 ? i : M2 - 1];
+            sum += (double)v * wv[k];
+        }
+        os[xx] = store_convert<T>(sum);
+    }
+#pragma unroll
+    for (int xx = 0; xx < K; xx++) {
+        if (xx < g.out_row0 || xx >= g.out_row0 + g.out_rows) continue;
+        T* orow = (T*)(out_f + (size_t)(xx - g.out_row0) * g.out_pitch);
+        orow[j] = os[xx];
+    }
+}
+
 }  // namespace lz

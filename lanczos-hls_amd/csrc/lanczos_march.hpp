@@ -51,59 +51,126 @@
 #define LZ_MARCH_SGPR_ATTR
 #endif
 
+// Ablation bits (FrameGeom::debug_skip, LANCZOS_DEBUG_SKIP) exist only in builds made with -DLZ_PROFILE_BITS: in the production
+// build every test of them is a compile-time false (the per-row `no_store` test alone was two scalar instructions and a
+// branch per output row).
+#ifdef LZ_PROFILE_BITS
+#define LZ_DBG(g, bits) (((g).debug_skip & (bits)) != 0)
+#else
+#define LZ_DBG(g, bits) false
+#endif
+
 namespace lz {
 
+// SPLIT (role-specialised waves): the first NHW waves of a workgroup run ONLY the H pass (+ fix-ups), the others ONLY the V
+// pass.  A V thread then owns its dword column for the whole march and carries its 2a-row register window from tick to
+// tick (no re-seeding: 5 ring reads + 20 conversions per tick saved), an H thread owns a unit of P = 8 input pixels
+// (13-pixel window: 1.6 conversions per computed sample instead of 2.5), and no wave pays the other role's per-tick
+// address and flag arithmetic.  Measured on config 2: see profiles/README.md (round 2).
 template <typename T, int C, int S, int A>
 struct MarchShape {
     static constexpr int NGRP = 2;                                  // V groups (whole waves each)
     static constexpr int MS = 2 * A * NGRP;                         // input rows per tick
+    static constexpr bool SPLIT = false;
+    static constexpr int P = 0, UPR = 0;                            // unit geometry: FastCfg's default
 };
 template <int A>
 struct MarchShape<uint8_t, 3, 3, A> {  // 288 dword columns: one V group of 4.5 waves
     static constexpr int NGRP = 1;
     static constexpr int MS = 12;
+    static constexpr bool SPLIT = false;
+    static constexpr int P = 0, UPR = 0;
 };
+#ifdef LZ_MARCH_SPLIT  // opt-in experiment (round 2): no faster than the 6-wave all-roles workgroup, slower on fix-up-heavy input
+template <>
+struct MarchShape<uint8_t, 3, 2, 3> {  // config 2: 3 H waves (12 rows x 16 units) + 3 V waves (192 dword columns x 12 rows)
+    static constexpr int NGRP = 1;
+    static constexpr int MS = 12;
+    static constexpr bool SPLIT = true;
+    static constexpr int P = 8, UPR = 16;
+};
+#elif defined(LZ_MARCH_WG8)
+// 8-wave workgroups: two waves on EVERY SIMD whatever SIMD the dispatcher starts a workgroup on (a 6-wave workgroup
+// puts 2+2+1+1), three workgroups = 24 waves per CU.  Strip = 320 output pixels (960 B = 240 dword columns x 2 V groups =
+// 480 threads; 12 rows x 40 units = 480 H units per tick).
+template <>
+struct MarchShape<uint8_t, 3, 2, 3> {
+    static constexpr int NGRP = 2;
+    static constexpr int MS = 12;
+    static constexpr bool SPLIT = false;
+    static constexpr int P = 4, UPR = 40;
+};
+#endif
 
 template <typename T, int C_, int S_, int A_>
 struct MarchCfg {
-    using F = FastCfg<T, C_, S_, A_>;  // unit geometry is shared with the tile kernel
+    using SH = MarchShape<T, C_, S_, A_>;
+    using F = FastCfg<T, C_, S_, A_, SH::P, SH::UPR>;  // unit geometry (the default one is shared with the tile kernel)
     static constexpr int C = C_, S = S_, A = A_;
+    static constexpr bool SPLIT = SH::SPLIT;
     static constexpr int SB = F::SB, TAPS = F::TAPS, P = F::P, UPR = F::UPR;
-    static constexpr int NGRP = MarchShape<T, C, S, A>::NGRP;
-    static constexpr int MS = MarchShape<T, C, S, A>::MS;
+    static constexpr int NGRP = SH::NGRP;
+    static constexpr int MS = SH::MS;
     static constexpr int MRG = MS / NGRP;
-    static constexpr int NVT = F::NVT;
+    static constexpr int NVT = F::TWB_OUT / 4;                       // V threads per group (dword columns)
     static constexpr int NU = MS * UPR;                              // H units per tick
-    static constexpr int NT_V = NVT * NGRP;
-    static constexpr int NT = (((NT_V > NU ? NT_V : NU) + 63) / 64) * 64;
+    static constexpr int NVT_PAD = NGRP == 1 ? NVT : ((NVT + 63) / 64) * 64;  // V groups start on wave boundaries
+    static constexpr int NT_V = NVT_PAD * NGRP;
+    static constexpr int NHW = SPLIT ? (NU + 63) / 64 : 0;           // SPLIT: waves [0, NHW) are H waves
+    static constexpr int NT = SPLIT ? NHW * 64 + ((NT_V + 63) / 64) * 64 : (((NT_V > NU ? NT_V : NU) + 63) / 64) * 64;
     static constexpr int NWAVES = NT / 64;
     static constexpr int RS = (2 * MS + TAPS - 1) <= 32 ? 32 : 64;   // ring rows: two ticks + the window
     static constexpr int IN_PITCH = F::IN_PITCH, H_PITCH = F::H_PITCH, CPR = F::CPR;
     static constexpr int NCH = MS * CPR;                             // 16-byte chunks of one tick's input
-    static constexpr int LOAD_IT = (NCH + NT - 1) / NT;
-    static constexpr int TIN_BYTES = LOAD_IT * NT * 16;              // >= MS*IN_PITCH: every lane commits a chunk
+    static constexpr int NLT = SPLIT ? NHW * 64 : NT;                // threads that move the input rows (SPLIT: the H
+                                                                     // waves -- they issue no stores, so the commit's
+                                                                     // vmcnt wait never sits behind this tick's stores)
+    static constexpr int LOAD_IT = (NCH + NLT - 1) / NLT;
+    static constexpr int TIN_BYTES = LOAD_IT * NLT * 16;             // >= MS*IN_PITCH: every loading lane commits a chunk
     // worklist entries per wave: one round of candidates.  (A list for all VEC rounds with a single dense pass
     // measured 13 % SLOWER, interleaved A/B on one device: the extra 7 KiB of LDS costs residency.)
     static constexpr int WL_ROUND = 64 * F::UNIT_IN_DW;               // most entries one round can add
     static constexpr int WLW = WL_ROUND + 128;                        // sparse flags: all rounds share ONE dense pass
+    static constexpr int NLISTS = SPLIT ? NHW : NWAVES;               // only waves that run the H pass keep a list
     static constexpr int LDS_TIN = 2 * TIN_BYTES;                    // double buffered
     static constexpr int LDS_HBUF = RS * H_PITCH;
-    static constexpr int LDS_WL = NWAVES * WLW * 2;
+    static constexpr int LDS_WL = NLISTS * WLW * 2;
     static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL;
     static constexpr int NNI = F::UNIT_OUT_S - P * C;                // non-integer-phase samples of a unit
+#ifdef LZ_MARCH_NO_LDSDMA
+    static constexpr bool LDSDMA = false;
+#else
+    static constexpr bool LDSDMA = true;   // input rows go HBM -> LDS directly (buffer_load_dwordx4 ... lds), no staging VGPRs
+#endif
+    // S = 2: the half-phase weights are symmetric (L is even and x = m + 1/2 exactly), so a chain is 3 exact pair sums and
+    // 3 fmafs -- the same 6 instructions, half the rounding steps: eps (and with it the near-integer fix-up rate) halves
+#ifdef LZ_MARCH_NO_SYM
+    static constexpr bool SYM = false;
+#else
+    static constexpr bool SYM = S == 2;
+#endif
+    // register budget (2nd launch bound = waves per SIMD the compiler must leave room for).  SPLIT: 4 workgroups x 6 waves
+    // = 24 waves per CU = 6 per SIMD -> 80 VGPRs; the others keep the compiler's own choice (72 for config 2 in round 1)
+#ifndef LZ_MARCH_MIN_WAVES
+#define LZ_MARCH_MIN_WAVES 6
+#endif
+    static constexpr int MIN_WAVES = SPLIT ? LZ_MARCH_MIN_WAVES : 1;
     static_assert(MS % NGRP == 0, "V groups split a tick evenly");
     static_assert(MRG * S <= 64, "the EXACT-mode redo mask has one bit per output row of a V group");
-    static_assert(NGRP == 1 || NVT % 64 == 0, "V groups must be whole waves");
+    static_assert(NGRP == 1 || NVT_PAD % 64 == 0, "V groups must be whole waves");
     static_assert(RS >= 2 * MS + TAPS - 1, "ring holds two ticks plus the window");
-    static_assert(64 % UPR == 0, "a wave covers whole unit rows");
-    static_assert(F::UNIT_OUT_S <= 64 && MS <= 32 && UPR <= 32, "worklist entry = row:5 | unit:5 | sample:6");
+    // worklist entry (16 bits) = row | unit | sample
+    static constexpr int WL_SMP_BITS = F::UNIT_OUT_S <= 32 ? 5 : 6;
+    static constexpr int WL_UNIT_BITS = UPR <= 16 ? 4 : (UPR <= 32 ? 5 : 6);
+    static_assert(F::UNIT_OUT_S <= 64 && UPR <= 64 && MS <= (1 << (16 - WL_SMP_BITS - WL_UNIT_BITS)), "worklist entry fits 16 bits");
+    static_assert(!SPLIT || (NGRP == 1 && MS % TAPS == 0), "carried V window: one group, the slot rotation realigns every tick");
 };
 
 // RIDE: the launch also carries the in-place prefix rows as extra workgroups behind the marching ones (small batches:
 // no separate k_prefix launch).  That variant rebuilds its per-lane indices every tick to stay inside the register
 // budget; the batch variant (RIDE = false) holds them in registers, which is 2-3 % faster when the chip is full.
 template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
-__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc,
+__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::MIN_WAVES)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc,
                                                                       int chunk_rows) {
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
@@ -195,7 +262,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     // strips of one band and spreading the bands round-robin was slower: 119 us.)  Profiling bit 4096 = natural order.
     // XCD x receives the ids x, x+8, ...: (nwg - x + 7) / 8 of them; they are renumbered consecutively behind XCD x-1's.
     const int xcd = wid & 7, xq = nwg >> 3, xr = nwg & 7;
-    const int lid = !(g.debug_skip & 4096) ? xcd * xq + (xcd < xr ? xcd : xr) + (wid >> 3) : wid;
+    const int lid = !LZ_DBG(g, 4096) ? xcd * xq + (xcd < xr ? xcd : xr) + (wid >> 3) : wid;
     const int frame = lid / g.wg_per_frame;
     const int tx = (lid - frame * g.wg_per_frame) % strips;
     const int chunk = (lid - frame * g.wg_per_frame) / strips;
@@ -229,23 +296,36 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     // instead of being held in registers across the other phases: the kernel sits on its 72-VGPR budget.)
     auto issue_loads = [&](int tick) {
         int t1 = tid;
-        if (RIDE || STAMP) asm volatile("" : "+v"(t1));
+        if (RIDE || STAMP || K::SPLIT) asm volatile("" : "+v"(t1));
 #pragma unroll
         for (int it = 0; it < K::LOAD_IT; it++) {
-            const int idx = t1 + it * K::NT;
+            const int idx = t1 + it * K::NLT;
             const int row = idx / K::CPR, ch = idx - row * K::CPR;
             const int gr = hb + tick * K::MS + row;
             const int gb = tile_gb0 + 16 * ch;
-            const bool ok = !(g.debug_skip & 16) && tick < ticks && idx < K::NCH && gr >= gr_min && gr <= gr_max &&
+            const bool ok = !LZ_DBG(g, 16) && tick < ticks && idx < K::NCH && gr >= gr_min && gr <= gr_max &&
                             gr <= h_last && gb >= 0 && gb < row_bytes;
             const unsigned off = ok ? (unsigned)((gr - g.in_row0) * g.in_pitch + gb) : 0xffffffffu;
-            pre[it] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);
+            if (K::LDSDMA) {
+                // LDS-DMA (buffer_load_dwordx4 ... lds): the tile image is lane-linear (chunk idx at byte idx * 16), so a
+                // wave-instruction lands 1 KiB at M0 = its first chunk -- no staging registers, no ds_write, and an
+                // out-of-range lane still writes its zeros.  Straight into the buffer H(tick-2) has finished with.
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    irsrc, (__attribute__((address_space(3))) void*)(smem + (tick & 1) * K::TIN_BYTES + (wave * 64 + it * K::NLT) * 16),
+                    16, off, 0, 0, 0);
+            } else {
+                pre[it] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);
+            }
         }
     };
     auto commit_loads = [&](int buf) {
+        if (K::LDSDMA) {  // the issuing wave's vmcnt covers its LDS-DMA; the tick's barrier publishes it to the other waves
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < K::LOAD_IT; it++)
-            *(u32x4*)(smem + buf * K::TIN_BYTES + (tid + it * K::NT) * 16) = pre[it];
+            *(u32x4*)(smem + buf * K::TIN_BYTES + (tid + it * K::NLT) * 16) = pre[it];
     };
 
     // ---- phase weights, pinned in VGPRs for the whole march.  Measured on gfx950 (scripts/probes/probe_valu3.hip): a VALU
@@ -262,7 +342,9 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     constexpr uint32_t HALF = SB == 1 ? 0x80u : 0x8000u;
     const uint32_t addc1 = (uint32_t)fc.vlim < HALF - 1 ? HALF - 1 - (uint32_t)fc.vlim : 0;
     // the chain bias and the SWAR masks live in VGPRs for the same reason (a literal is a constant-bus read too)
-    float hbias = fc.bias;
+    // SB == 1: the H chain carries eps - 0.5 (see the byte convert in hpass); SYM: the paired chain's (smaller) eps
+    float hbias = SB == 1 ? (K::SYM ? fc.vbias_rne_p : fc.vbias_rne) : (K::SYM ? fc.bias_p : fc.bias);
+    const float near2 = K::SYM ? fc.near2_p : fc.near2;
     constexpr uint32_t LOW = SB == 1 ? 0x7f7f7f7fu : 0x7fff7fffu;
     constexpr uint32_t TOP = SB == 1 ? 0x80808080u : 0x80008000u;
     const uint32_t addc = SB == 1 ? addc1 * 0x01010101u : addc1 * 0x00010001u;
@@ -273,9 +355,9 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
         const uint8_t* tin = smem + (tick & 1) * K::TIN_BYTES;
         const int h0 = hb + tick * K::MS;           // first H row of the tick
         int t3 = tid;
-        if (RIDE || STAMP) asm volatile("" : "+v"(t3));
+        if (RIDE || STAMP || K::SPLIT) asm volatile("" : "+v"(t3));
         const int row = t3 / K::UPR, u = t3 % K::UPR;
-        const bool unit_ok = t3 < K::NU && h0 + row <= h_last && !(g.debug_skip & 1);
+        const bool unit_ok = t3 < K::NU && h0 + row <= h_last && !LZ_DBG(g, 1);
         uint32_t im = 0;      // undecided integer-phase samples: bit (8*e*SB + i) <-> own input sample i*VEC + e
         bool near = false;    // some non-integer-phase sample of the unit is within eps of an integer
         if (unit_ok) {
@@ -337,32 +419,57 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                 ow[i] = w;
             }
             float dmin = 1.0f;
+            uint32_t dminu = 0x7f800000u;  // SB == 1: smallest fract(acc) - 0.5 seen, compared as unsigned bit patterns
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 float fch[F::WIN_PX];
 #pragma unroll
-                for (int t = 0; t < F::WIN_PX; t++) fch[t] = (float)win_sample<T, F::MIS, F::NW>(wd, t * C + c);
+                for (int t = 0; t < F::WIN_PX; t++) {
+                    fch[t] = (float)win_sample<T, F::MIS, F::NW>(wd, t * C + c);
+                    // SYM: keep the conversion a v_cvt_f32_ubyteN.  Left alone, the compiler rewrites (float)a + (float)b as
+                    // (float)(a + b) with SDWA byte adds + v_cvt_f32_u32 -- fewer instructions, 45 % more time (measured)
+                    if (K::SYM) asm volatile("" : "+v"(fch[t]));
+                }
 #pragma unroll
                 for (int q = 0; q < K::P * S; q++) {
                     const int p = q / S, ph = q % S;
                     if (ph == 0) continue;
                     float acc = hbias;
+                    if (K::SYM) {
 #pragma unroll
-                    for (int j = 0; j < TAPS; j++) {
-                        const int k = f32_tap_order(j, TAPS);  // outside in: the bound of fc.bias assumes this order
-                        acc = __builtin_fmaf(wv[ph][k], fch[p + k], acc);
+                        for (int k = 0; k < A; k++)  // outside in; the pair sums are exact (<= 2 * max sample)
+                            acc = __builtin_fmaf(wv[ph][k], fch[p + k] + fch[p + TAPS - 1 - k], acc);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TAPS; j++) {
+                            const int k = f32_tap_order(j, TAPS);  // outside in: the bound of fc.bias assumes this order
+                            acc = __builtin_fmaf(wv[ph][k], fch[p + k], acc);
+                        }
                     }
-                    // below 1 / above max the store clamps: nothing to decide there
-                    const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, F::MAXV + 0.5f);
-                    const float fl = __builtin_floorf(xc);
-                    dmin = __builtin_fminf(dmin, xc - fl);
                     const int o = q * C + c;
-                    if (SB == 1) ow[o / 4] = __builtin_amdgcn_cvt_pk_u8_f32(fl, o % 4, ow[o / 4]);
-                    else ow[o / 2] |= (unsigned)fl << (16 * (o % 2));
+                    if (SB == 1) {
+                        // acc = sum + (eps - 0.5) + chain error, |chain error| < eps: the saturating round-to-nearest-even
+                        // byte convert is floor(sum + eps') with eps' in (0, 2 eps) -- the reference's truncating store --
+                        // unless sum lies within 2 eps below an integer, i.e. fract(acc) in [0.5, 0.5 + 2 eps): undecided.
+                        // fract and the subtraction are exact; a negative difference has its sign bit set and loses the
+                        // unsigned minimum.  (Sums outside [0, max] may flag spuriously: the exact chain clamps like the store.)
+                        acc = __builtin_fmaxf(acc, 0.0f);  // sum + eps' < 1/2: the store is 0 whatever the sum (keeps black regions,
+                                                           // whose sums are exactly 0, off the undecided list)
+                        const float g = __builtin_amdgcn_fractf(acc) - 0.5f;
+                        const uint32_t gu = __builtin_bit_cast(uint32_t, g);
+                        dminu = gu < dminu ? gu : dminu;
+                        ow[o / 4] = __builtin_amdgcn_cvt_pk_u8_f32(acc, o % 4, ow[o / 4]);
+                    } else {
+                        // below 1 / above max the store clamps: nothing to decide there
+                        const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, F::MAXV + 0.5f);
+                        const float fl = __builtin_floorf(xc);
+                        dmin = __builtin_fminf(dmin, xc - fl);
+                        ow[o / 2] |= (unsigned)fl << (16 * (o % 2));
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            near = dmin < fc.near2;
+            near = SB == 1 ? dminu < __builtin_bit_cast(uint32_t, near2) : dmin < near2;
             // widest aligned LDS stores the unit allows
             if (F::UNIT_OUT_DW % 2 == 0) {
 #pragma unroll
@@ -409,20 +516,21 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                 }
             }
         }
-        if (g.debug_skip & (32 | 256 | 512)) {  // profiling bits: 32 no flags at all, 256 no near flags, 512 no integer flags
-            if (g.debug_skip & (32 | 512)) im = 0;
-            if (g.debug_skip & (32 | 256)) near = false;
+        if (LZ_DBG(g, 32 | 256 | 512)) {  // profiling bits: 32 no flags at all, 256 no near flags, 512 no integer flags
+            if (LZ_DBG(g, 32 | 512)) im = 0;
+            if (LZ_DBG(g, 32 | 256)) near = false;
         }
 
         // ---- wave-private compaction of the undecided samples, then the exact chain, densely
-        if (__any(im != 0 || near) && !(g.debug_skip & 2)) {
+        if (__any(im != 0 || near) && !LZ_DBG(g, 2)) {
             int cnt = 0;  // uniform
             auto flush = [&]() {
                 const T* tinT = (const T*)tin;
                 T* hbufT = (T*)hbuf;
                 for (int i = lane; i < cnt; i += 64) {
                     const unsigned e = wlw[i];
-                    const int erow = e >> 11, eu = (e >> 6) & 31, o = e & 63;
+                    const int erow = e >> (K::WL_SMP_BITS + K::WL_UNIT_BITS), eu = (e >> K::WL_SMP_BITS) & ((1 << K::WL_UNIT_BITS) - 1),
+                              o = e & ((1 << K::WL_SMP_BITS) - 1);
                     const int q = o / C, c = o - q * C;          // output pixel / channel inside the unit
                     const int xl = eu * (K::P * S) + q;          // output pixel inside the strip
                     const int xx = tx * F::TWP_OUT + xl;
@@ -456,7 +564,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                 }
                 cnt = 0;
             };
-            const unsigned ent0 = ((unsigned)row << 11) | ((unsigned)u << 6);
+            const unsigned ent0 = ((unsigned)row << (K::WL_SMP_BITS + K::WL_UNIT_BITS)) | ((unsigned)u << K::WL_SMP_BITS);
             auto append = [&](bool flag, int o) {  // o wave-uniform: output sample of the unit
                 const unsigned long long m = __ballot(flag);
                 if (m == 0) return;
@@ -491,40 +599,56 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     };
 
     // =================================================================== VPASS of one tick
-    const int grp_w = K::NGRP == 1 ? 0 : wave * 64 / K::NVT;  // the wave's V group (NGRP > 1: groups are whole waves)
+    const int grp_w = K::NGRP == 1 ? 0 : wave * 64 / K::NVT_PAD;  // the wave's V group (NGRP > 1: groups are whole waves)
     const __amdgpu_buffer_rsrc_t orsrc =
         __builtin_amdgcn_make_buffer_rsrc(out_f, 0, (unsigned)(g.out_rows * g.out_pitch), 0x00020000);
-    float vbias = (SB == 1 && !EXACT) ? fc.vbias_rne : fc.bias;
+    float vbias = (SB == 1 && !EXACT) ? (K::SYM ? fc.vbias_rne_p : fc.vbias_rne) : (K::SYM ? fc.bias_p : fc.bias);
     asm volatile("" : "+v"(vbias));
 
-    auto vpass = [&](int tick) {
-        int t2 = tid;
+    // SPLIT: the V window lives across ticks (the slot rotation realigns every MS = k * TAPS rows)
+    float win[TAPS][F::VEC];
+    uint32_t raw[TAPS];
+    if (K::SPLIT) {
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) {
+            raw[k] = 0;
+#pragma unroll
+            for (int e = 0; e < F::VEC; e++) win[k][e] = 0.0f;
+        }
+    }
+    // returns (per lane; lane 0 decides for the wave) whether this call issued EXACTLY MRG * S store instructions and no
+    // other vector-memory instruction: the march loop then waits for its input prefetch with a counted vmcnt
+    auto vpass = [&](int tick) -> bool {
+        int t2 = K::SPLIT ? tid - K::NHW * 64 : tid;
         if (RIDE || STAMP) asm volatile("" : "+v"(t2));
         const int grp = K::NGRP == 1 ? (t2 < K::NVT ? 0 : 1) : grp_w;
-        const int col = t2 - grp * K::NVT;
+        const int col = t2 - grp * K::NVT_PAD;
         const unsigned col_b = (unsigned)(tx * F::TWB_OUT + col * 4);
-        const bool col_ok = grp < K::NGRP && col_b + 4 <= (unsigned)(g.out_w * C * SB);
-        if (!col_ok || (g.debug_skip & 4)) return;
+        const bool col_ok = grp < K::NGRP && col < K::NVT && col_b + 4 <= (unsigned)(g.out_w * C * SB);
+        if (!col_ok || LZ_DBG(g, 4)) return false;
         constexpr int HP = K::H_PITCH / 4;
         // m handled this tick: [m_lo, m_lo + MS) with m_lo = m_b - (2a-1) + tick*MS; this group's share:
         const int m_g = m_b - (TAPS - 1) + tick * K::MS + grp * K::MRG;
-        if (m_g + K::MRG <= m_b || m_g >= m_e) return;  // uniform
+        if (m_g + K::MRG <= m_b || m_g >= m_e) return false;  // uniform
         const uint32_t* hcol = (const uint32_t*)hbuf + col;
-        float win[TAPS][F::VEC];
-        uint32_t raw[TAPS];
         auto unpack = [&](int slot_i, uint32_t w) {
             raw[slot_i] = w;
 #pragma unroll
-            for (int e = 0; e < F::VEC; e++) win[slot_i][e] = (float)((w >> (8 * SB * e)) & F::SMASK);
+            for (int e = 0; e < F::VEC; e++) {
+                win[slot_i][e] = (float)((w >> (8 * SB * e)) & F::SMASK);
+                if (K::SYM) asm volatile("" : "+v"(win[slot_i][e]));  // see hpass: no integer pair sums
+            }
         };
         auto ring = [&](int r) { return hcol[((r - hb) & (K::RS - 1)) * HP]; };  // H row r of this column
         // rows m_g-a+1 .. m_g+a-1 seed the window; rows before hb were never produced: only read for m < m_b,
         // whose outputs are not stored
+        if (!K::SPLIT) {
 #pragma unroll
-        for (int k = 0; k < TAPS - 1; k++) unpack(k, ring(m_g - A + 1 + k));
+            for (int k = 0; k < TAPS - 1; k++) unpack(k, ring(m_g - A + 1 + k));
+        }
         // every output row of this group's share lies inside the chunk and the stored range: no per-row tests
         const bool interior = m_g >= m_b && m_g + K::MRG <= m_e && m_g * S >= y_lo && (m_g + K::MRG) * S <= y_hi;
-        const bool no_store = (g.debug_skip & 8) != 0;
+        const bool no_store = LZ_DBG(g, 8);
         int soff = (m_g * S - g.out_row0) * g.out_pitch;  // scalar byte offset of the current output row
         // two instances of the row loop: the interior one (the common case) carries no range tests at all --
         // the per-row scalar compare/select chains cost more issue slots than the arithmetic they guarded
@@ -564,10 +688,16 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
 #pragma unroll
                         for (int e = 0; e < F::VEC; e++) {
                             float acc = vbias;
+                            if (K::SYM) {
 #pragma unroll
-                            for (int j = 0; j < TAPS; j++) {
-                                const int k = f32_tap_order(j, TAPS);
-                                acc = __builtin_fmaf(wv[ph][k], win[(i + k) % TAPS][e], acc);
+                                for (int k = 0; k < A; k++)
+                                    acc = __builtin_fmaf(wv[ph][k], win[(i + k) % TAPS][e] + win[(i + TAPS - 1 - k) % TAPS][e], acc);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < TAPS; j++) {
+                                    const int k = f32_tap_order(j, TAPS);
+                                    acc = __builtin_fmaf(wv[ph][k], win[(i + k) % TAPS][e], acc);
+                                }
                             }
                             accs[e] = acc;
                         }
@@ -582,7 +712,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                             for (int e = 0; e < F::VEC; e++) {
                                 const float xc = __builtin_amdgcn_fmed3f(accs[e], 0.5f, F::MAXV + 0.5f);
                                 const float fl = __builtin_floorf(xc);
-                                if (EXACT) undecided |= (xc - fl) < fc.near2;
+                                if (EXACT) undecided |= (xc - fl) < near2;
                                 packed |= (unsigned)fl << (8 * SB * e);
                             }
                         }
@@ -625,6 +755,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
                 __builtin_amdgcn_raw_buffer_store_b32(packed, orsrc, col_b, (y - g.out_row0) * g.out_pitch, LZ_STORE_AUX);
             }
         }
+        return interior && !EXACT && !LZ_DBG(g, 8);
     };
 
     // diagnostic build only: residency census -- when and where (XCC / SE / CU) this workgroup ran
@@ -636,6 +767,37 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
         census_xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
     }
     // =================================================================== the march
+    if (K::SPLIT) {
+        // Role-specialised waves.  Both roles pass the same barriers (one after the prologue's loads, one after H(0), one
+        // per tick); between two barriers the H waves produce tick t+1's rows in the ring while the V waves consume tick
+        // t's.  The H waves also move the input rows (prefetch two ticks ahead, commit after their H pass).
+        const bool is_h = wave < K::NHW;   // wave-uniform
+        if (is_h) {
+            issue_loads(0);
+            commit_loads(0);
+            issue_loads(1);
+            commit_loads(1);
+        }
+        __syncthreads();
+        if (is_h) hpass(0);
+        __syncthreads();
+        if (is_h) {
+            __builtin_amdgcn_s_setprio(3);  // the ring feeds every V wave's next tick: H first (measured in round 1)
+            for (int tick = 0; tick < ticks; tick++) {
+                issue_loads(tick + 2);
+                if (tick + 1 < ticks) hpass(tick + 1);
+                commit_loads(tick & 1);
+                __syncthreads();
+            }
+        } else {
+            __builtin_amdgcn_s_setprio(2);
+            for (int tick = 0; tick < ticks; tick++) {
+                vpass(tick);
+                __syncthreads();
+            }
+        }
+        return;
+    }
     issue_loads(0);
     commit_loads(0);
     issue_loads(1);
@@ -656,7 +818,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
     };
     for (int tick = 0; tick < ticks; tick++) {
         const unsigned long long t0 = stamp();
-        issue_loads(tick + 2);              // lands in the buffer HPASS(tick) has finished with
+        if (!K::LDSDMA) issue_loads(tick + 2);  // lands in the buffer HPASS(tick) has finished with
         const unsigned long long t1 = stamp();
         // Wave priority by phase (measured, interleaved on one device: H=3/V=2/else=0 is 11-13 % faster than all
         // equal): the H pass feeds the ring every other wave's next V pass waits for, so it goes first.
@@ -664,15 +826,22 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT)) LZ_MARCH_SGPR_ATTR void
         if (tick + 1 < ticks) hpass(tick + 1);
         __builtin_amdgcn_s_setprio(0);
         const unsigned long long t2 = stamp();
-        // commit BEFORE the V pass issues its stores: vmcnt retires in order, so waiting for the prefetch here
-        // only waits for the previous tick's (long finished) stores, never for this tick's
-        commit_loads(tick & 1);
+        // Register staging: commit BEFORE the V pass issues its stores.  LDS-DMA: the prefetch is ISSUED here, between the
+        // previous tick's stores and this tick's -- vmcnt retires in order, so after the V pass "all but the MRG * S youngest"
+        // is exactly "the prefetch has landed", and the wave never waits for a store to be acknowledged by memory (waiting
+        // with vmcnt(0) in front of the V pass stood behind the previous tick's stores: 'no loads' ablation -15 us).
+        if (K::LDSDMA) issue_loads(tick + 2);
+        else commit_loads(tick & 1);
         const unsigned long long t3 = stamp();
         __builtin_amdgcn_s_setprio(2);
-        vpass(tick);
+        const bool full = vpass(tick);
         __builtin_amdgcn_s_setprio(0);
+        if (K::LDSDMA) {
+            if (__builtin_amdgcn_readfirstlane((int)full)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K::MRG * S) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const unsigned long long t4 = stamp();
-        if (!(g.debug_skip & 128)) __syncthreads();  // (profiling bit 128: no barrier -- results are then wrong)
+        if (!LZ_DBG(g, 128)) __syncthreads();  // (profiling bit 128: no barrier -- results are then wrong)
         const unsigned long long t5 = stamp();
         if (STAMP) {
             tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3; tsum[4] += t5 - t4;
@@ -714,7 +883,7 @@ inline int march_chunk_rows(int m_rows, int strips, int frames, int ms, int slot
 
 template <typename T, int C, int S, int A>
 inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, const TapTables& t,
-                                 const FastConsts& fc, hipStream_t stream, bool* prefix_fused) {
+                                 const FastConsts& fc, hipStream_t stream, bool* prefix_fused, bool query_only) {
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
     FrameGeom g = g_in;
@@ -770,6 +939,7 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
             *prefix_fused = false;
         }
     }
+    if (query_only) return hipSuccess;  // the caller only wanted *prefix_fused (it launches the prefix rows itself, first)
     dim3 grid(g.n_main + g.prefix_blocks_per_frame * g.frames);
     static const int extra_lds = getenv("LANCZOS_EXTRA_LDS") ? atoi(getenv("LANCZOS_EXTRA_LDS")) : 0;  // occupancy experiments
     static bool attr_done[2][64] = {};
@@ -816,11 +986,11 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
 }
 
 inline hipError_t march_launch(const lanczos_desc& d, const FrameGeom& g, const TapTables& t, const FastConsts& fc,
-                               hipStream_t stream, bool* prefix_fused) {
+                               hipStream_t stream, bool* prefix_fused, bool query_only = false) {
     *prefix_fused = false;
 #define X(T, C, S, A)                                                                               \
     if (d.bytes_per_sample == (int)sizeof(T) && d.channels == C && d.scale_n == S && d.a == A)      \
-        return march_launch_t<T, C, S, A>(d, g, t, fc, stream, prefix_fused);
+        return march_launch_t<T, C, S, A>(d, g, t, fc, stream, prefix_fused, query_only);
     LZ_FAST_CONFIGS(X)
 #undef X
     return hipErrorNotSupported;

@@ -81,6 +81,19 @@ int validate(const lanczos_desc* d) {
     return LANCZOS_OK;
 }
 
+double f32_chain_error_bound_ordered(const double* w, const int* order, int n, double maxv) {
+    const double u = std::ldexp(1.0, -24);  // f32 unit roundoff
+    double P = 0.5 + 1e-3, err = 0, wq = 0;
+    for (int j = 0; j < n; j++) {
+        const int k = order[j];
+        const double wf = (double)(float)w[k];
+        P += maxv * std::fabs(wf);
+        err += u * (P + err);
+        wq += std::fabs(wf - w[k]) * maxv;
+    }
+    return 1.02 * (err + wq);  // 2 % slack
+}
+
 double f32_chain_error_bound(const double* w, int ntaps, double maxv) {
     // acc_0 = bias; acc_j = fl(wf[k_j] * v[k_j] + acc_{j-1}) with ONE rounding per fmaf:
     //   |acc_j - (wf*v + acc_{j-1})| <= u * |wf*v + acc_{j-1}| <= u * P_j,   P_j = |bias| + maxv * sum_{i<=j} |wf[k_i]| (+ earlier errors)

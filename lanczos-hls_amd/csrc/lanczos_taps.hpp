@@ -48,6 +48,8 @@ int gcd(int a, int b);  // stb.cpp:9-12 (the reference reduces SCALE_N/SCALE_D w
 constexpr int f32_tap_order(int step, int ntaps) { return (step & 1) ? ntaps - 1 - step / 2 : step / 2; }
 // Rigorous bound on |f32 chain - real sum| for samples in [0,maxv], taps added in f32_tap_order, start value |bias| <= 0.5
 double f32_chain_error_bound(const double* w, int ntaps, double maxv);
+// The same bound for a chain that adds w[order[0]], w[order[1]], ... w[order[n-1]] in that order (n taps used)
+double f32_chain_error_bound_ordered(const double* w, const int* order, int n, double maxv);
 
 // Largest centre sample v0 for which the integer-phase double chain can still end below v0
 // (SURVEY.md Q4); every v0 above it provably comes out unchanged.  wi[k] = L(a-1-k), k = 0..2a-1.
