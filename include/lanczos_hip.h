@@ -51,11 +51,21 @@ extern "C" {
 #define LANCZOS_MODE_LSB1 0   /* default: horizontal pass bit-exact, vertical pass f32 accumulators;
                                  every output sample within +-1 LSB of the reference software path */
 #define LANCZOS_MODE_EXACT 1  /* every output sample bit-identical to the reference software path */
+#define LANCZOS_MODE_HLS 2    /* the semantics of the reference's HLS pipeline instead (lanczos.cpp:86-98): vertical pass
+                                 first (lanczos.cpp:21-51), ROM weights L(|o*D - i*N| / N) (kernel.cpp:40-59), zero rows /
+                                 samples above and left of the image, the last row / sample repeated below and right of it
+                                 (worker.cpp:147-153,176-188,244,256-265), each pass's sum clamped to [min,max] of its two
+                                 centre taps -- the de-ringing of README.md:4 (worker.cpp:66-74,103-111) -- a real-valued
+                                 intermediate, truncating final store (worker.cpp:118-130).  Computed in f64 with exact phase
+                                 stepping; the hardware's ap_fixed arithmetic is NOT emulated.  Parity unpinned by the
+                                 reference (the HLS path cannot be built without Xilinx headers); checked against
+                                 oracle/lanczos_hls_model.c.  No in-place prefix: lanczos_inplace_rows() is 0. */
 
 /* which kernel family served the last call (lanczos_last_kernel) */
 #define LANCZOS_KERNEL_NONE 0
 #define LANCZOS_KERNEL_GENERIC 1  /* table-driven, any rational scale > 1, f64 throughout (always exact) */
 #define LANCZOS_KERNEL_FAST 2     /* specialised: integer scale, LDS-staged tiles, f32 taps + exact fallback */
+#define LANCZOS_KERNEL_HLS 3      /* LANCZOS_MODE_HLS: V-then-H with de-ringing clamps, f64 */
 
 typedef struct lanczos_ctx lanczos_ctx; /* opaque: device, stream, cached tap tables, staging buffers */
 

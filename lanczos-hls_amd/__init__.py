@@ -21,8 +21,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LANCZOS_LIB") or os.path.join(_HERE, "liblanczos_hip.so")
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM = range(6)
-MODE_LSB1, MODE_EXACT = 0, 1
-KERNEL_NONE, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2
+MODE_LSB1, MODE_EXACT, MODE_HLS = 0, 1, 2
+KERNEL_NONE, KERNEL_GENERIC, KERNEL_FAST, KERNEL_HLS = 0, 1, 2, 3
 
 # every symbol include/lanczos_hip.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = [

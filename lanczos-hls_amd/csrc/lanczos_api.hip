@@ -21,13 +21,14 @@
 #include "lanczos_layout.hpp"
 #include "lanczos_march.hpp"
 #include "lanczos_generic.hpp"
+#include "lanczos_hls.hpp"
 #include "lanczos_kernels_common.hpp"
 #include "lanczos_taps.hpp"
 
 namespace {
 
 struct PlanKey {
-    int in_w, in_h, out_w, out_h, channels, bps, sn, sd, a;
+    int in_w, in_h, out_w, out_h, channels, bps, sn, sd, a, hls;
     bool operator<(const PlanKey& o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
 
@@ -87,8 +88,9 @@ namespace {
 int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
     PlanKey key;
     memset(&key, 0, sizeof(key));
+    const bool hls = d->mode == LANCZOS_MODE_HLS;
     key = PlanKey{d->in_w, d->in_h, d->out_w, d->out_h, d->channels, d->bytes_per_sample,
-                  d->scale_n, d->scale_d, d->a};
+                  d->scale_n, d->scale_d, d->a, hls ? 1 : 0};
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) {
         *out = it->second;
@@ -96,9 +98,14 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
     }
     Plan* p = new (std::nothrow) Plan();
     if (!p) return LANCZOS_ERR_NOMEM;
-    lz::build_axis(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &p->H);
-    lz::build_axis(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &p->V);
-    p->prefix = lz::prefix_info(p->V);
+    if (hls) {  // ROM weights, exact stepping, no in-place prefix (lanczos_hls.hpp)
+        lz::build_axis_hls(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &p->H);
+        lz::build_axis_hls(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &p->V);
+    } else {
+        lz::build_axis(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &p->H);
+        lz::build_axis(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &p->V);
+        p->prefix = lz::prefix_info(p->V);
+    }
     const int taps = 2 * d->a;
     // one device block: h_first | v_first | h_w | v_w  (8-byte aligned sections)
     size_t off_hf = 0;
@@ -107,7 +114,7 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
     size_t off_vw = off_hw + (size_t)d->out_w * taps * 8;
     size_t off_xw = off_vw + (size_t)d->out_h * taps * 8;
     size_t total = off_xw + (size_t)lz::kFastMaxS * lz::kMaxTaps * 8;
-    p->fast_ok = lz::fast_prepare(*d, p->H, p->V, &p->fast);
+    p->fast_ok = !hls && lz::fast_prepare(*d, p->H, p->V, &p->fast);
     std::vector<uint8_t> host(total, 0);
     if (p->fast_ok) {  // row 0: integer phase, row ph: phase ph
         memcpy(host.data() + off_xw, p->fast.wi, lz::kMaxTaps * 8);
@@ -205,6 +212,7 @@ int lanczos_validate(const lanczos_desc* d) { return lz::validate(d); }
 
 int lanczos_inplace_rows(const lanczos_desc* d) {
     if (lz::validate(d) != LANCZOS_OK) return -1;
+    if (d->mode == LANCZOS_MODE_HLS) return 0;  // the HLS pipeline has no in-place pass
     lz::AxisTaps V;
     lz::build_axis(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &V);
     return lz::prefix_info(V).K;
@@ -216,6 +224,11 @@ int lanczos_strip_input_rows(const lanczos_desc* d, int out_row0, int out_rows, 
     if (!in_row0 || !in_rows || out_row0 < 0 || out_rows <= 0 || out_row0 + out_rows > d->out_h)
         return LANCZOS_ERR_BAD_ARG;
     lz::AxisTaps V;
+    if (d->mode == LANCZOS_MODE_HLS) {
+        lz::build_axis_hls(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &V);
+        strip_input_rows(V, d->a, d->in_h, out_row0, out_rows, lz::PrefixInfo(), in_row0, in_rows);
+        return LANCZOS_OK;
+    }
     lz::build_axis(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &V);
     strip_input_rows(V, d->a, d->in_h, out_row0, out_rows, lz::prefix_info(V), in_row0, in_rows);
     return LANCZOS_OK;
@@ -244,7 +257,9 @@ int lanczos_taps_host(const lanczos_desc* d, int axis, int32_t* first, double* w
     if (rc != LANCZOS_OK) return rc;
     if (!first || !weights || (axis != 0 && axis != 1)) return LANCZOS_ERR_BAD_ARG;
     lz::AxisTaps t;
-    if (axis == 0)
+    if (d->mode == LANCZOS_MODE_HLS)
+        lz::build_axis_hls(axis == 0 ? d->in_w : d->in_h, axis == 0 ? d->out_w : d->out_h, d->scale_n, d->scale_d, d->a, &t);
+    else if (axis == 0)
         lz::build_axis(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &t);
     else
         lz::build_axis(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &t);
@@ -408,7 +423,7 @@ int lanczos_last_kernel(const lanczos_ctx* ctx) { return ctx ? ctx->last_kernel 
 int lanczos_last_hip_error(const lanczos_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
 
 int lanczos_force_kernel(lanczos_ctx* ctx, int family) {
-    if (!ctx || family < LANCZOS_KERNEL_NONE || family > LANCZOS_KERNEL_FAST) return LANCZOS_ERR_BAD_ARG;
+    if (!ctx || family < LANCZOS_KERNEL_NONE || family > LANCZOS_KERNEL_FAST) return LANCZOS_ERR_BAD_ARG;  // (_HLS follows the mode)
     ctx->force = family;
     return LANCZOS_OK;
 }
@@ -505,6 +520,21 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
         }
     }
 
+    if (d->mode == LANCZOS_MODE_HLS) {
+        if (ctx->force == LANCZOS_KERNEL_FAST || ctx->force == LANCZOS_KERNEL_GENERIC) return LANCZOS_ERR_UNSUPPORTED;
+        if (d->channels > 4 || 2 * d->a > 2 * lz::kMaxA) return LANCZOS_ERR_UNSUPPORTED;
+        const int tiles_x = (d->out_w + lz::kHlsTileW - 1) / lz::kHlsTileW;
+        const int tiles_y = (rows + lz::kHlsTileH - 1) / lz::kHlsTileH;
+        if (frames > 65535) return LANCZOS_ERR_UNSUPPORTED;
+        dim3 grid(tiles_x * tiles_y, frames);
+        if (d->bytes_per_sample == 1)
+            hipLaunchKernelGGL(lz::k_hls<uint8_t>, grid, dim3(lz::kHlsThreads), 0, stream, g, p->dev);
+        else
+            hipLaunchKernelGGL(lz::k_hls<uint16_t>, grid, dim3(lz::kHlsThreads), 0, stream, g, p->dev);
+        LZ_HIP(ctx, hipGetLastError());
+        ctx->last_kernel = LANCZOS_KERNEL_HLS;
+        return LANCZOS_OK;
+    }
     bool prefix_fused = false;
     bool use_fast = p->fast_ok && ctx->force != LANCZOS_KERNEL_GENERIC &&
                     lz::fast_supports(*d, g);

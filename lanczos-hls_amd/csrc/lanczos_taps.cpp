@@ -42,6 +42,37 @@ void build_axis(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* 
     }
 }
 
+// kernel.cpp:12-18 at x = k/N, tabulated like init_lanczos_kernel (kernel.cpp:40-45).  Same expressions, same order and
+// the same -ffp-contract=off as oracle/lanczos_hls_model.c (the checker), so the device's f64 chains match it bit for bit.
+double hls_rom(int k, int a, int scale_n) {
+    if (k < 0) k = -k;
+    if (k == 0) return 1.0;
+    if (k >= a * scale_n) return 0.0;  // ROM[LANCZOS_A*SCALE_N] = 0 (kernel.cpp:44)
+    if (k % scale_n == 0) return 0.0;  // hls::sinpi of an integer is exactly 0
+    const double x = (double)k / scale_n;
+    const double s1 = std::sin(M_PI * x);
+    const double s2 = std::sin(M_PI * x / a);
+    const double c = (double)a / (M_PI * M_PI);
+    return c * s1 * s2 / (x * x);
+}
+
+void build_axis_hls(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* t) {
+    t->in_n = in_n;
+    t->out_n = out_n;
+    t->a = a;
+    t->first.assign(out_n, 0);
+    t->w.assign((size_t)out_n * 2 * a, 0.0);
+    for (int o = 0; o < out_n; o++) {
+        const int first = (int)(((long long)o * scale_d) / scale_n) - a + 1;
+        t->first[o] = first;
+        for (int k = 0; k < 2 * a; k++) {
+            long long idx = (long long)o * scale_d - (long long)(first + k) * scale_n;  // kernel.cpp:56
+            if (idx < 0) idx = -idx;
+            t->w[(size_t)o * 2 * a + k] = idx > (long long)a * scale_n ? 0.0 : hls_rom((int)idx, a, scale_n);
+        }
+    }
+}
+
 PrefixInfo prefix_info(const AxisTaps& v) {
     PrefixInfo p;
     const int taps = 2 * v.a;
@@ -67,7 +98,7 @@ int validate(const lanczos_desc* d) {
     if (d->bytes_per_sample != 1 && d->bytes_per_sample != 2) return LANCZOS_ERR_BAD_ARG;
     if (d->a < 2 || d->a > kMaxA) return LANCZOS_ERR_BAD_ARG;
     if (d->scale_n <= 0 || d->scale_d <= 0) return LANCZOS_ERR_BAD_ARG;
-    if (d->mode != LANCZOS_MODE_LSB1 && d->mode != LANCZOS_MODE_EXACT) return LANCZOS_ERR_BAD_ARG;
+    if (d->mode != LANCZOS_MODE_LSB1 && d->mode != LANCZOS_MODE_EXACT && d->mode != LANCZOS_MODE_HLS) return LANCZOS_ERR_BAD_ARG;
     // the harness rejects images whose size is not the compiled-in one (full_TB.h:115-118);
     // here: the output must be the input scaled by N/D (integer division, as OUT_WIDTH = IN_WIDTH*3)
     if ((long long)d->in_w * d->scale_n / d->scale_d != d->out_w) return LANCZOS_ERR_BAD_ARG;

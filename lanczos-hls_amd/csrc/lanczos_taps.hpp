@@ -30,6 +30,12 @@ struct AxisTaps {
 // x = (double)o / ((double)n/d)  (full_TB.h:57,70 with SCALE of lanczos.h:112)
 void build_axis(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* t);
 
+// LANCZOS_MODE_HLS: first = floor(o*D/N) - a + 1 (exact integer stepping), weights from the ROM of kernel.cpp:40-59,
+// ROM[k] = a/pi^2 * sinpi(k/N) * sinpi(k/(aN)) / (k/N)^2 at k = |o*D - i*N| (1 at k = 0, exactly 0 at whole-pixel
+// distances and at k = a*N).  NO zeroing of out-of-range taps: the HLS borders substitute samples, not weights.
+double hls_rom(int k, int a, int scale_n);
+void build_axis_hls(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* t);
+
 struct PrefixInfo {
     int K = 0;   // output rows [0,K) read rows i > xx, i.e. already-written OUTPUT rows (full_TB.h:67-77)
     int M = 0;   // those reads reach output rows < M  (M >= K)

@@ -1,0 +1,146 @@
+/*
+ * oracle/lanczos_hls_model.c -- see lanczos_hls_model.h.  TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+ * Compile with -ffp-contract=off (the product's table builder uses the same expressions under the same flag, so the
+ * device's f64 chains reproduce these sums bit for bit).
+ */
+#define _GNU_SOURCE
+#include "lanczos_hls_model.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* kernel.cpp:12-18 raw_lanczos_kernel at x = k/N, and the ROM of kernel.cpp:40-45.  hls::sinpi is exact at integers:
+ * the weights at whole pixel distances are exactly 0 (the software model's sin(M_PI*x) leaves ~1e-17 there). */
+double oracle_hls_rom(int k, int a, int scale_n) {
+    if (k < 0) k = -k;
+    if (k == 0) return 1.0;
+    if (k >= a * scale_n) return 0.0;          /* ROM[LANCZOS_A*SCALE_N] = 0, kernel.cpp:44 */
+    if (k % scale_n == 0) return 0.0;          /* sinpi(integer) == 0 */
+    const double x = (double)k / scale_n;
+    const double s1 = sin(M_PI * x);
+    const double s2 = sin(M_PI * x / a);
+    const double c = (double)a / (M_PI * M_PI);
+    return c * s1 * s2 / (x * x);
+}
+
+/* kernel.cpp:50-59: index |output_idx*SCALE_D - input_idx*SCALE_N| */
+double oracle_hls_weight(int i, int o, int a, int scale_n, int scale_d) {
+    long long k = (long long)o * scale_d - (long long)i * scale_n;
+    if (k < 0) k = -k;
+    if (k > (long long)a * scale_n) return 0.0; /* cannot happen inside the window (see header) */
+    return oracle_hls_rom((int)k, a, scale_n);
+}
+
+typedef struct {
+    const oracle_cfg* c;
+    const void* in;
+    void* out;
+    int bytes;
+    int y0, y1;
+} hls_job;
+
+#define HLS_MAX_TAPS 16
+
+/* one output row: vertical pass of every input column (ColWorkers::exec, worker.cpp:138-155 with compute()
+ * worker.cpp:45-78), then the horizontal pass along it (RowWorkers::exec, worker.cpp:225-236 with compute_() :81-115 and
+ * clamp_to_byte :118-130). */
+#define HLS_DEFINE(T, SFX)                                                                                             \
+    static void hls_rows_##SFX(const hls_job* j) {                                                                    \
+        const oracle_cfg* c = j->c;                                                                                    \
+        const int C = c->channels, a = c->a, taps = 2 * a, W = c->in_w, H = c->in_h;                                  \
+        const T* in = (const T*)j->in;                                                                                 \
+        T* out = (T*)j->out;                                                                                           \
+        double* vrow = (double*)malloc(sizeof(double) * (size_t)W * C);                                                \
+        for (int y = j->y0; y < j->y1; y++) {                                                                          \
+            /* window rows floor(y*D/N)-a+1 .. +a; rows < 0 are the zero priming (worker.cpp:176-188), rows > H-1     \
+             * the saturated push (worker.cpp:147-153) */                                                             \
+            const int fy = (int)(((long long)y * c->scale_d) / c->scale_n);                                            \
+            double wv[HLS_MAX_TAPS];                                                                                    \
+            int rr[HLS_MAX_TAPS];                                                                                       \
+            for (int k = 0; k < taps; k++) {                                                                           \
+                const int r = fy - a + 1 + k;                                                                          \
+                wv[k] = oracle_hls_weight(r, y, a, c->scale_n, c->scale_d);                                            \
+                rr[k] = r;                                                                                             \
+            }                                                                                                          \
+            for (int i = 0; i < W * C; i++) {                                                                          \
+                double px[HLS_MAX_TAPS];                                                                                \
+                for (int k = 0; k < taps; k++) {                                                                       \
+                    const int r = rr[k];                                                                               \
+                    px[k] = r < 0 ? 0.0 : (double)in[(size_t)(r > H - 1 ? H - 1 : r) * W * C + i];                    \
+                }                                                                                                      \
+                double acc = 0;                                                                                        \
+                for (int k = 0; k < taps; k++) acc += wv[k] * px[k];       /* worker.cpp:58-64 */                      \
+                const double lo = ORC_HLS_MIN(px[a - 1], px[a]), hi = ORC_HLS_MAX(px[a - 1], px[a]);                   \
+                vrow[i] = acc < lo ? lo : (acc > hi ? hi : acc);           /* worker.cpp:66-74 */                      \
+            }                                                                                                          \
+            for (int x = 0; x < c->out_w; x++) {                                                                       \
+                const int fx = (int)(((long long)x * c->scale_d) / c->scale_n);                                        \
+                double wh[HLS_MAX_TAPS];                                                                                \
+                for (int k = 0; k < taps; k++) wh[k] = oracle_hls_weight(fx - a + 1 + k, x, a, c->scale_n, c->scale_d); \
+                for (int ch = 0; ch < C; ch++) {                                                                       \
+                    double px[HLS_MAX_TAPS];                                                                            \
+                    for (int k = 0; k < taps; k++) {                                                                   \
+                        const int q = fx - a + 1 + k;  /* left: zeros (worker.cpp:256-265); right: last again (:244) */ \
+                        px[k] = q < 0 ? 0.0 : vrow[(size_t)(q > W - 1 ? W - 1 : q) * C + ch];                          \
+                    }                                                                                                  \
+                    double acc = 0;                                                                                    \
+                    for (int k = 0; k < taps; k++) acc += wh[k] * px[k];   /* worker.cpp:95-101 */                     \
+                    const double lo = ORC_HLS_MIN(px[a - 1], px[a]), hi = ORC_HLS_MAX(px[a - 1], px[a]);               \
+                    const double v = acc < lo ? lo : (acc > hi ? hi : acc);/* worker.cpp:103-111 */                    \
+                    out[((size_t)y * c->out_w + x) * C + ch] = (T)floor(v);/* worker.cpp:118-130: truncation */        \
+                }                                                                                                      \
+            }                                                                                                          \
+        }                                                                                                              \
+        free(vrow);                                                                                                    \
+    }
+
+#define ORC_HLS_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define ORC_HLS_MAX(a, b) ((a) > (b) ? (a) : (b))
+HLS_DEFINE(uint8_t, u8)
+HLS_DEFINE(uint16_t, u16)
+
+static void* hls_thread(void* p) {
+    const hls_job* j = (const hls_job*)p;
+    if (j->bytes == 1) hls_rows_u8(j);
+    else hls_rows_u16(j);
+    return NULL;
+}
+
+static int hls_run(const oracle_cfg* c, const void* in, void* out, int bytes, int threads) {
+    if (!c || !in || !out || c->in_w <= 0 || c->in_h <= 0 || c->out_w <= 0 || c->out_h <= 0 || c->channels <= 0 ||
+        c->a <= 0 || 2 * c->a > HLS_MAX_TAPS || c->scale_n <= 0 || c->scale_d <= 0)
+        return -1;
+    if (threads < 1) threads = 1;
+    if (threads > c->out_h) threads = c->out_h;
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    hls_job jobs[256];
+    for (int t = 0; t < threads; t++) {
+        jobs[t].c = c;
+        jobs[t].in = in;
+        jobs[t].out = out;
+        jobs[t].bytes = bytes;
+        jobs[t].y0 = (int)((long long)c->out_h * t / threads);
+        jobs[t].y1 = (int)((long long)c->out_h * (t + 1) / threads);
+    }
+    if (threads == 1) {
+        hls_thread(&jobs[0]);
+        return 0;
+    }
+    for (int t = 0; t < threads; t++)
+        if (pthread_create(&th[t], NULL, hls_thread, &jobs[t]) != 0) return -2;
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    return 0;
+}
+
+int oracle_hls_expected_hwc_u8(const oracle_cfg* cfg, const uint8_t* in, uint8_t* out, int threads) {
+    return hls_run(cfg, in, out, 1, threads);
+}
+int oracle_hls_expected_hwc_u16(const oracle_cfg* cfg, const uint16_t* in, uint16_t* out, int threads) {
+    return hls_run(cfg, in, out, 2, threads);
+}

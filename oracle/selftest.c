@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "lanczos_hls_model.h"
 #include "lanczos_oracle.h"
 
 static const int kShapes[][6] = {
@@ -49,6 +50,12 @@ int main(void) {
             if (oracle_outofplace_hwc_u8(&c, in8, out8) != 0) return 3;
             printf("oop %dx%dx%d %d/%d a%d t%d %016llx K=%d\n", c.in_w, c.in_h, c.channels, c.scale_n, c.scale_d, c.a,
                    threads, (unsigned long long)oracle_fnv1a64(out8, n_out), oracle_inplace_rows(&c));
+            if (oracle_hls_expected_hwc_u8(&c, in8, out8, threads) != 0) return 3;
+            printf("hls8 %dx%dx%d %d/%d a%d t%d %016llx\n", c.in_w, c.in_h, c.channels, c.scale_n, c.scale_d, c.a, threads,
+                   (unsigned long long)oracle_fnv1a64(out8, n_out));
+            if (oracle_hls_expected_hwc_u16(&c, in16, out16, threads) != 0) return 3;
+            printf("hls16 %dx%dx%d %d/%d a%d t%d %016llx\n", c.in_w, c.in_h, c.channels, c.scale_n, c.scale_d, c.a, threads,
+                   (unsigned long long)oracle_fnv1a64(out16, n_out * 2));
             free(in8);
             free(out8);
             free(in16);

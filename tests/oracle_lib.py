@@ -39,8 +39,8 @@ def build_oracle():
 def lib():
     global _lib
     if _lib is None:
-        src = os.path.join(ORACLE_DIR, "lanczos_oracle.c")
-        if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(src) > os.path.getmtime(ORACLE_SO):
+        srcs = [os.path.join(ORACLE_DIR, n) for n in ("lanczos_oracle.c", "lanczos_hls_model.c", "lanczos_hls_model.h")]
+        if (not os.path.exists(ORACLE_SO)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
             build_oracle()
         L = ctypes.CDLL(ORACLE_SO)
         P = ctypes.POINTER(OracleCfg)
@@ -60,6 +60,14 @@ def lib():
         L.oracle_fnv1a64.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         L.oracle_lcg_fill_u8.restype = None
         L.oracle_lcg_fill_u8.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+        for name in ("oracle_hls_expected_hwc_u8", "oracle_hls_expected_hwc_u16"):
+            f = getattr(L, name)
+            f.restype = ctypes.c_int
+            f.argtypes = [P, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.oracle_hls_rom.restype = ctypes.c_double
+        L.oracle_hls_rom.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.oracle_hls_weight.restype = ctypes.c_double
+        L.oracle_hls_weight.argtypes = [ctypes.c_int] * 5
         L.oracle_lcg_fill_u16.restype = None
         L.oracle_lcg_fill_u16.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         _lib = L
@@ -114,6 +122,26 @@ def expected_hwc_u16(c, img, threads=1):
     rc = lib().oracle_expected_hwc_u16(ctypes.byref(c), img.ctypes.data, out.ctypes.data, threads)
     assert rc == 0, rc
     return out
+
+
+def hls_expected_hwc(c, img, threads=1):
+    """oracle/lanczos_hls_model.c: the HLS pipeline's semantics (V-then-H, ROM weights, de-ring clamps, zero / repeat
+    borders) in ideal arithmetic.  PARITY UNPINNED by the reference."""
+    img = np.ascontiguousarray(img)
+    assert img.shape == (c.in_h, c.in_w, c.channels) and img.dtype in (np.uint8, np.uint16)
+    out = np.empty((c.out_h, c.out_w, c.channels), dtype=img.dtype)
+    fn = lib().oracle_hls_expected_hwc_u8 if img.dtype == np.uint8 else lib().oracle_hls_expected_hwc_u16
+    rc = fn(ctypes.byref(c), img.ctypes.data, out.ctypes.data, threads)
+    assert rc == 0, rc
+    return out
+
+
+def hls_rom(k, a, scale_n):
+    return float(lib().oracle_hls_rom(k, a, scale_n))
+
+
+def hls_weight(i, o, a, scale_n, scale_d):
+    return float(lib().oracle_hls_weight(i, o, a, scale_n, scale_d))
 
 
 def outofplace_hwc_u8(c, img):

@@ -1,0 +1,149 @@
+"""LANCZOS_MODE_HLS: the semantics of the reference's HLS pipeline (lanczos.cpp:86-98 and worker.cpp / kernel.cpp) --
+vertical pass first, ROM weights, zero / repeat borders, de-ringing clamps, real-valued intermediate.
+
+PARITY UNPINNED BY THE REFERENCE: the HLS path needs Xilinx headers (ap_fixed.h, hls_stream.h, hls_math.h) that neither the
+reference tree nor this image has, and the reference holds no output of it.  The checker is the ideal-arithmetic restatement
+oracle/lanczos_hls_model.c; on top of it, properties that follow from the cited lines alone:
+  * de-ringing: every output sample lies in [min, max] of the 2x2 input samples around its position (worker.cpp:66-74,103-111)
+  * integer phases pass the input through (ROM[0] = 1, ROM at whole-pixel distances = 0, kernel.cpp:12-18,40-45)
+  * where no clamp is active and no border is touched the result is the plain separable Lanczos sum
+"""
+import numpy as np
+import pytest
+
+import lanczos_hls_amd as L
+import oracle_lib as O
+import patterns as P
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the model itself
+def test_rom_matches_kernel_cpp_formula():
+    """kernel.cpp:12-18,40-45: ROM[k] = a/pi^2 * sinpi(k/N) sinpi(k/(aN)) / (k/N)^2; 1 at 0; 0 at k = a*N and at whole pixels."""
+    for a in (2, 3, 4):
+        for n in (2, 3, 4, 5):
+            assert O.hls_rom(0, a, n) == 1.0
+            assert O.hls_rom(a * n, a, n) == 0.0
+            for k in range(1, a * n):
+                x = k / n
+                want = 0.0 if k % n == 0 else a / np.pi ** 2 * np.sin(np.pi * x) * np.sin(np.pi * x / a) / x ** 2
+                assert abs(O.hls_rom(k, a, n) - want) < 1e-15
+                # the same function as the software model's sinc*sinc (full_TB.h:51-53), up to rounding
+                assert abs(O.hls_rom(k, a, n) - L.lanczos_kernel(x, a)) < 1e-15
+            assert O.hls_rom(-3, a, n) == O.hls_rom(3, a, n)
+
+
+def test_product_tables_equal_the_model(tmp_path):
+    """lanczos_taps_host in HLS mode: first = floor(o*D/N) - a + 1, weights = ROM[|o*D - i*N|], bit for bit the checker's."""
+    for (w, h, sn, sd, a) in [(40, 30, 2, 1, 3), (30, 20, 3, 1, 2), (33, 21, 4, 3, 3), (24, 18, 5, 2, 4)]:
+        d = L.make_desc(w, h, 3, sn, sd, a, 1, L.MODE_HLS)
+        for axis, n_in, n_out in ((0, w, d.out_w), (1, h, d.out_h)):
+            first, wt = L.taps_host(d, axis)
+            for o in range(n_out):
+                assert first[o] == (o * sd) // sn - a + 1
+                for k in range(2 * a):
+                    assert wt[o, k] == O.hls_weight(int(first[o]) + k, o, a, sn, sd)
+        assert L.inplace_rows(d) == 0
+
+
+def _model(img, sn, sd, a, threads=4):
+    h, w, c = img.shape
+    return O.hls_expected_hwc(O.cfg(w, h, w * sn // sd, h * sn // sd, c, a, sn, sd), img, threads)
+
+
+def test_model_dering_bound_and_passthrough():
+    rng = np.random.default_rng(3)
+    for (w, h, c, sn, sd, a) in [(37, 23, 3, 2, 1, 3), (20, 16, 1, 3, 1, 2), (25, 18, 4, 4, 3, 3), (16, 12, 3, 2, 1, 4)]:
+        img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        out = _model(img, sn, sd, a)
+        oh, ow = out.shape[:2]
+        fy = (np.arange(oh) * sd) // sn
+        fx = (np.arange(ow) * sd) // sn
+        y1 = np.minimum(fy + 1, h - 1)
+        x1 = np.minimum(fx + 1, w - 1)
+        quad = np.stack([img[fy][:, fx], img[fy][:, x1], img[y1][:, fx], img[y1][:, x1]]).astype(int)
+        assert np.all(out >= quad.min(0)) and np.all(out <= quad.max(0))       # de-ringing
+        if sd == 1:                                                            # integer phases: the input itself
+            assert np.array_equal(out[::sn, ::sn], img)
+    flat = np.full((12, 15, 3), 77, np.uint8)                                   # flat image: clamps pin every sum to 77
+    assert np.all(_model(flat, 2, 1, 3) == 77)
+
+
+def test_model_equals_plain_separable_sum_where_nothing_clamps():
+    """Smooth ramp, interior samples: no clamp is active and no border tap is used, so the result is
+    floor(sum_x w_x * sum_y w_y * in) -- computed here independently with numpy."""
+    h, w, sn, a = 24, 28, 2, 3
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (40 + 3 * xx + 2 * yy).astype(np.uint8)[..., None]
+    out = _model(img, sn, 1, a)[..., 0]
+    f = img[..., 0].astype(np.float64)
+    for y in range(2 * a * sn, (h - 2 * a) * sn):
+        for x in range(2 * a * sn, (w - 2 * a) * sn, 3):
+            fy, fx = y // sn, x // sn
+            wy = np.array([O.hls_weight(fy - a + 1 + k, y, a, sn, 1) for k in range(2 * a)])
+            wx = np.array([O.hls_weight(fx - a + 1 + k, x, a, sn, 1) for k in range(2 * a)])
+            v = f[fy - a + 1:fy + a + 1, fx - a + 1:fx + a + 1]
+            s = float(wx @ (wy @ v))
+            # the ramp is linear and the weights nearly sum to 1: the sums stay inside the centre-tap interval
+            assert abs(out[y, x] - np.floor(s + 1e-9)) <= 1 and abs(out[y, x] - s) < 1.0 + 1e-9
+
+
+# ------------------------------------------------------------------------------------------------ GPU: HIP vs the model
+@pytest.fixture(scope="module")
+def ctx():
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+SHAPES = [(200, 120, 3, 2, 1, 3), (160, 90, 3, 3, 1, 3), (128, 96, 3, 2, 1, 2), (96, 64, 4, 2, 1, 4), (150, 100, 3, 4, 3, 3),
+          (120, 80, 1, 2, 1, 3), (100, 75, 3, 3, 2, 3), (64, 33, 1, 5, 2, 4), (515, 131, 3, 2, 1, 3), (7, 5, 3, 2, 1, 3),
+          (1, 1, 3, 2, 1, 3), (3, 2, 4, 3, 1, 3), (2, 9, 1, 2, 1, 4)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pattern", ["noise", "gradient", "blocks"])
+def test_hls_mode_matches_the_model(ctx, pattern):
+    for (w, h, c, sn, sd, a) in SHAPES:
+        img = P.ALL_U8[pattern](h, w, c)
+        want = _model(img, sn, sd, a, threads=8)
+        got = ctx.resample(img, sn, sd, a, L.MODE_HLS)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), (pattern, w, h, c, sn, sd, a, int(np.abs(got.astype(int) - want).max()))
+        assert ctx.last_kernel() == L.KERNEL_HLS
+
+
+@pytest.mark.gpu
+def test_hls_mode_u16_batches_and_strips(ctx):
+    img = P.noise(64, 96, 4, seed=4, dtype=np.uint16)
+    want = _model(img, 2, 1, 4)
+    assert np.array_equal(ctx.resample(img, 2, 1, 4, L.MODE_HLS), want)
+    frames = np.stack([P.noise(50, 70, 3, seed=60 + i) for i in range(3)])
+    got = ctx.resample(frames, 3, 1, 3, L.MODE_HLS)
+    for i in range(3):
+        assert np.array_equal(got[i], _model(frames[i], 3, 1, 3))
+    img8 = P.noise(96, 120, 3, seed=8)                      # row strips: rows are independent, halo rows are clamped
+    want8 = _model(img8, 2, 1, 3)
+    parts = []
+    for i in range(4):
+        d = L.make_desc(120, 96, 3, 2, 1, 3, 1, L.MODE_HLS, out_row0=48 * i, out_rows=48)
+        r0, n = L.strip_input_rows(d, d.out_row0, d.out_rows)
+        parts.append(ctx.resample_strip(img8[r0:r0 + n], d))
+    assert np.array_equal(np.concatenate(parts), want8)
+
+
+@pytest.mark.gpu
+def test_hls_mode_full_size_properties(ctx):
+    """Config 2's frame in HLS mode: de-ringing bound on every sample and pass-through at integer phases, no CPU model run."""
+    img = P.gradient_noise(1080, 1920, 3)
+    out = ctx.resample(img, 2, 1, 3, L.MODE_HLS)
+    assert np.array_equal(out[::2, ::2], img)
+    fy = np.arange(2160) // 2
+    fx = np.arange(3840) // 2
+    y1, x1 = np.minimum(fy + 1, 1079), np.minimum(fx + 1, 1919)
+    lo = np.minimum(np.minimum(img[fy][:, fx], img[fy][:, x1]), np.minimum(img[y1][:, fx], img[y1][:, x1]))
+    hi = np.maximum(np.maximum(img[fy][:, fx], img[fy][:, x1]), np.maximum(img[y1][:, fx], img[y1][:, x1]))
+    assert np.all(out >= lo) and np.all(out <= hi)
+    # against the default (software-model) mode: the same image up to the clamps, the truncated intermediate and the borders
+    soft = ctx.resample(img, 2, 1, 3, L.MODE_EXACT)
+    d = np.abs(out[40:-40, 40:-40].astype(int) - soft[40:-40, 40:-40].astype(int))
+    assert d.max() <= 6 and d.mean() < 1.0
