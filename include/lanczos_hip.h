@@ -139,6 +139,27 @@ int lanczos_resample_planar_device(lanczos_ctx* ctx, const lanczos_desc* d, cons
 int lanczos_u8(lanczos_ctx* ctx, const uint8_t* in, int in_w, int in_h, int channels,
                uint8_t* out, int out_w, int out_h, int a);
 
+/* ---- several devices of one node (lanczos_multi.hip) ----
+ * The reference has no parallelism beyond HLS unrolling (ROW_WORKERS, lanczos.cpp:72-82); this is the north star's
+ * multi-GPU scheduler.  The resample shards with no data-path collective: */
+#define LANCZOS_SPLIT_FRAMES 0  /* a batch of frames in per-device blocks (BASELINE config 4) */
+#define LANCZOS_SPLIT_ROWS 1    /* every frame in output row strips + input halo (BASELINE config 5) */
+typedef struct lanczos_multi lanczos_multi; /* opaque: one lanczos_ctx per device (+ RCCL communicators for the root path) */
+/* partition arithmetic (host only, no GPU): part `part` of `parts` */
+int lanczos_partition_frames(int frames, int parts, int part, int* first, int* count);
+int lanczos_partition_rows(const lanczos_desc* d, int parts, int part, int* out_row0, int* out_rows, int* in_row0,
+                           int* in_rows);
+int lanczos_multi_create(lanczos_multi** m, const int* devices, int n_devices);
+int lanczos_multi_destroy(lanczos_multi* m);
+int lanczos_multi_devices(const lanczos_multi* m);
+/* Host buffers (`frames` whole frames back to back): one host thread per device, every device copies only its share over
+ * its own PCIe link.  Results are those of lanczos_resample_host on one device. */
+int lanczos_resample_multi_host(lanczos_multi* m, const lanczos_desc* d, const void* in, void* out, int frames, int split);
+/* Frames resident on the ROOT device (devices[0]): scatter (RCCL ncclSend/ncclRecv group over xGMI) -> resample on every
+ * device -> gather.  Synchronous.  compute_ms / total_ms may be NULL.  librccl is loaded on first use (n_devices > 1). */
+int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const void* d_in_root, void* d_out_root, int frames,
+                                int split, double* compute_ms, double* total_ms);
+
 /* ---- measurement / introspection ---- */
 /* When enabled, every lanczos_resample_device call brackets its main kernel with HIP events on the
  * launch stream. lanczos_timing_read synchronises, returns and resets the sums. */

@@ -34,7 +34,10 @@ ABI_SYMBOLS = [
     "lanczos_resample_planar_device", "lanczos_u8", "lanczos_timing_enable", "lanczos_timing_read",
     "lanczos_last_kernel", "lanczos_last_hip_error", "lanczos_force_kernel", "lanczos_strerror",
     "lanczos_version",
+    "lanczos_partition_frames", "lanczos_partition_rows", "lanczos_multi_create", "lanczos_multi_destroy",
+    "lanczos_multi_devices", "lanczos_resample_multi_host", "lanczos_resample_multi_root",
 ]
+SPLIT_FRAMES, SPLIT_ROWS = 0, 1
 
 
 class LanczosError(RuntimeError):
@@ -114,6 +117,14 @@ def _lib():
         L.lanczos_last_hip_error.argtypes = [c_void_p]
         L.lanczos_force_kernel.argtypes = [c_void_p, c_int]
         L.lanczos_strerror.argtypes = [c_int]
+        L.lanczos_partition_frames.argtypes = [c_int, c_int, c_int, PI, PI]
+        L.lanczos_partition_rows.argtypes = [PD, c_int, c_int, PI, PI, PI, PI]
+        L.lanczos_multi_create.argtypes = [ctypes.POINTER(c_void_p), PI, c_int]
+        L.lanczos_multi_destroy.argtypes = [c_void_p]
+        L.lanczos_multi_devices.argtypes = [c_void_p]
+        L.lanczos_resample_multi_host.argtypes = [c_void_p, PD, c_void_p, c_void_p, c_int, c_int]
+        L.lanczos_resample_multi_root.argtypes = [c_void_p, PD, c_void_p, c_void_p, c_int, c_int,
+                                                  ctypes.POINTER(c_double), ctypes.POINTER(c_double)]
         L.lanczos_strerror.restype = ctypes.c_char_p
         L.lanczos_version.argtypes = []
         L.lanczos_version.restype = ctypes.c_char_p
@@ -289,6 +300,54 @@ class Context:
 
     def force_kernel(self, family):
         _check(_lib().lanczos_force_kernel(self._h, family), "lanczos_force_kernel")
+
+
+def partition_frames(frames, parts, part):
+    f0, cnt = ctypes.c_int(), ctypes.c_int()
+    _check(_lib().lanczos_partition_frames(frames, parts, part, ctypes.byref(f0), ctypes.byref(cnt)), "lanczos_partition_frames")
+    return f0.value, cnt.value
+
+
+def partition_rows(desc, parts, part):
+    v = [ctypes.c_int() for _ in range(4)]
+    _check(_lib().lanczos_partition_rows(ctypes.byref(desc), parts, part, *[ctypes.byref(x) for x in v]), "lanczos_partition_rows")
+    return tuple(x.value for x in v)   # out_row0, out_rows, in_row0, in_rows
+
+
+class MultiContext:
+    """lanczos_multi: one context per device of one node (frames or row strips split over them, no data-path collective)."""
+
+    def __init__(self, devices):
+        self._h = ctypes.c_void_p()
+        arr = (ctypes.c_int * len(devices))(*devices)
+        _check(_lib().lanczos_multi_create(ctypes.byref(self._h), arr, len(devices)), "lanczos_multi_create")
+
+    def close(self):
+        if self._h:
+            _lib().lanczos_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def resample(self, frames_hwc, scale_n, scale_d, a, mode=MODE_LSB1, split=SPLIT_FRAMES):
+        x = np.ascontiguousarray(frames_hwc)
+        f, h, w, c = x.shape
+        d = make_desc(w, h, c, scale_n, scale_d, a, x.dtype.itemsize, mode)
+        out = np.empty((f, d.out_h, d.out_w, c), dtype=x.dtype)
+        _check(_lib().lanczos_resample_multi_host(self._h, ctypes.byref(d), x.ctypes.data, out.ctypes.data, f, split),
+               "lanczos_resample_multi_host")
+        return out
+
+    def resample_root(self, desc, d_in_root, d_out_root, frames, split=SPLIT_FRAMES):
+        """Device pointers on devices[0]; returns (compute_ms, total_ms)."""
+        cm, tm = ctypes.c_double(), ctypes.c_double()
+        _check(_lib().lanczos_resample_multi_root(self._h, ctypes.byref(desc), d_in_root, d_out_root, frames, split,
+                                                  ctypes.byref(cm), ctypes.byref(tm)), "lanczos_resample_multi_root")
+        return cm.value, tm.value
 
 
 _default_ctx = None

@@ -1,0 +1,345 @@
+// lanczos_multi.hip -- several MI355X of one node behind the same C ABI (include/lanczos_hip.h, "multi-device").
+//
+// The reference has no parallelism beyond HLS unrolling (ROW_WORKERS rows per strip, lanczos.cpp:72-82); this is the
+// scheduler the north star adds: the resample shards with NO data-path collective --
+//   LANCZOS_SPLIT_FRAMES  a batch of frames is cut into per-device blocks          (BASELINE config 4)
+//   LANCZOS_SPLIT_ROWS    every frame is cut into output row strips + input halo   (BASELINE config 5;
+//                         lanczos_strip_input_rows, only strip 0 holds the in-place prefix rows)
+// One lanczos_ctx and one host thread per device.  Two data paths:
+//   * lanczos_resample_multi_host: every device copies its share straight from / to the caller's host buffers over its OWN
+//     PCIe link (no root GPU in the way);
+//   * lanczos_resample_multi_root: frames resident on device 0; one exchange step each way over xGMI with RCCL
+//     (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd in one process, ncclCommInitAll) -- SURVEY.md 8(e).  librccl is
+//     loaded on first use (dlopen), so single-GPU users never touch it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/lanczos_hip.h"
+
+namespace {
+
+// ---- the slice of rccl.h this file uses (declared here so that the library has no link-time dependency on librccl)
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+enum { kNcclUint8 = 1 };
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    bool load() {
+        if (lib) return true;
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return false;
+#define SYM(field, name) *(void**)(&field) = dlsym(lib, name)
+        SYM(CommInitAll, "ncclCommInitAll");
+        SYM(CommDestroy, "ncclCommDestroy");
+        SYM(GroupStart, "ncclGroupStart");
+        SYM(GroupEnd, "ncclGroupEnd");
+        SYM(Send, "ncclSend");
+        SYM(Recv, "ncclRecv");
+#undef SYM
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+    }
+};
+
+}  // namespace
+
+struct lanczos_multi {
+    std::vector<int> devices;
+    std::vector<lanczos_ctx*> ctx;
+    // root path
+    Rccl rccl;
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;
+    std::vector<void*> d_in, d_out;         // per-device shard buffers (device 0 works in place on the root buffers)
+    std::vector<size_t> d_in_bytes, d_out_bytes;
+    int last_hip = 0;
+};
+
+extern "C" {
+
+int lanczos_partition_frames(int frames, int parts, int part, int* first, int* count) {
+    if (frames < 0 || parts < 1 || part < 0 || part >= parts || !first || !count) return LANCZOS_ERR_BAD_ARG;
+    const int base = frames / parts, rem = frames % parts;     // earlier parts take the remainder
+    *first = part * base + (part < rem ? part : rem);
+    *count = base + (part < rem ? 1 : 0);
+    return LANCZOS_OK;
+}
+
+int lanczos_partition_rows(const lanczos_desc* d, int parts, int part, int* out_row0, int* out_rows, int* in_row0,
+                           int* in_rows) {
+    int rc = lanczos_validate(d);
+    if (rc != LANCZOS_OK) return rc;
+    if (parts < 1 || part < 0 || part >= parts || !out_row0 || !out_rows || !in_row0 || !in_rows) return LANCZOS_ERR_BAD_ARG;
+    if (d->out_rows != 0 && !(d->out_row0 == 0 && d->out_rows == d->out_h)) return LANCZOS_ERR_BAD_ARG;  // whole frames only
+    // equal strips; the first one is widened to hold the in-place prefix recurrence (rows [0, M) must be in one place:
+    // full_TB.h:67-77) -- K + 2a + 2 rows always cover M
+    const int K = lanczos_inplace_rows(d);
+    const int min_first = K > 0 ? K + 2 * d->a + 2 : 0;
+    auto bound = [&](int i) {
+        long long b = (long long)d->out_h * i / parts;
+        if (i >= 1 && i < parts && b < min_first) b = min_first < d->out_h ? min_first : d->out_h;
+        return (int)b;
+    };
+    const int r0 = bound(part), r1 = part + 1 == parts ? d->out_h : bound(part + 1);
+    *out_row0 = r0;
+    *out_rows = r1 > r0 ? r1 - r0 : 0;
+    *in_row0 = *in_rows = 0;
+    if (*out_rows == 0) return LANCZOS_OK;
+    return lanczos_strip_input_rows(d, r0, *out_rows, in_row0, in_rows);
+}
+
+int lanczos_multi_create(lanczos_multi** out, const int* devices, int n_devices) {
+    if (!out || !devices || n_devices < 1 || n_devices > 64) return LANCZOS_ERR_BAD_ARG;
+    *out = nullptr;
+    lanczos_multi* m = new (std::nothrow) lanczos_multi();
+    if (!m) return LANCZOS_ERR_NOMEM;
+    for (int i = 0; i < n_devices; i++) {
+        lanczos_ctx* c = nullptr;
+        const int rc = lanczos_create(&c, devices[i]);
+        if (rc != LANCZOS_OK) {
+            for (lanczos_ctx* p : m->ctx) lanczos_destroy(p);
+            delete m;
+            return rc;
+        }
+        m->devices.push_back(devices[i]);
+        m->ctx.push_back(c);
+    }
+    *out = m;
+    return LANCZOS_OK;
+}
+
+int lanczos_multi_destroy(lanczos_multi* m) {
+    if (!m) return LANCZOS_ERR_BAD_ARG;
+    for (size_t i = 0; i < m->streams.size(); i++) {
+        (void)hipSetDevice(m->devices[i]);
+        if (m->streams[i]) (void)hipStreamSynchronize(m->streams[i]);
+    }
+    for (size_t i = 0; i < m->comms.size(); i++)
+        if (m->comms[i]) m->rccl.CommDestroy(m->comms[i]);
+    for (size_t i = 0; i < m->d_in.size(); i++) {
+        (void)hipSetDevice(m->devices[i]);
+        if (m->d_in[i]) (void)hipFree(m->d_in[i]);
+        if (m->d_out[i]) (void)hipFree(m->d_out[i]);
+        if (m->streams[i]) (void)hipStreamDestroy(m->streams[i]);
+    }
+    for (lanczos_ctx* c : m->ctx) lanczos_destroy(c);
+    delete m;
+    return LANCZOS_OK;
+}
+
+int lanczos_multi_devices(const lanczos_multi* m) { return m ? (int)m->ctx.size() : 0; }
+
+// Host buffers in, host buffers out: `frames` whole frames back to back (what lanczos_resample_host takes).  One thread per
+// device; every device moves only its own share over its own PCIe link.
+int lanczos_resample_multi_host(lanczos_multi* m, const lanczos_desc* d, const void* in, void* out, int frames, int split) {
+    if (!m || !in || !out || frames <= 0) return LANCZOS_ERR_BAD_ARG;
+    int rc = lanczos_validate(d);
+    if (rc != LANCZOS_OK) return rc;
+    if (split != LANCZOS_SPLIT_FRAMES && split != LANCZOS_SPLIT_ROWS) return LANCZOS_ERR_BAD_ARG;
+    if (d->out_rows != 0 && !(d->out_row0 == 0 && d->out_rows == d->out_h)) return LANCZOS_ERR_BAD_ARG;
+    const int n = (int)m->ctx.size();
+    const size_t in_frame = lanczos_in_frame_bytes(d), out_frame = lanczos_out_frame_bytes(d);
+    const size_t in_pitch = (size_t)d->in_w * d->channels * d->bytes_per_sample;
+    const size_t out_pitch = (size_t)d->out_w * d->channels * d->bytes_per_sample;
+    std::vector<int> rcs(n, LANCZOS_OK);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n; i++) {
+        th.emplace_back([&, i]() {
+            lanczos_desc dd = *d;
+            dd.out_row0 = dd.out_rows = 0;
+            if (split == LANCZOS_SPLIT_FRAMES) {
+                int f0, cnt;
+                lanczos_partition_frames(frames, n, i, &f0, &cnt);
+                if (cnt > 0)
+                    rcs[i] = lanczos_resample_host(m->ctx[i], &dd, (const uint8_t*)in + (size_t)f0 * in_frame,
+                                                   (uint8_t*)out + (size_t)f0 * out_frame, cnt);
+            } else {
+                int r0, rows, i0, irows;
+                rcs[i] = lanczos_partition_rows(&dd, n, i, &r0, &rows, &i0, &irows);
+                if (rcs[i] != LANCZOS_OK || rows == 0) return;
+                dd.out_row0 = r0;
+                dd.out_rows = rows;
+                for (int f = 0; f < frames && rcs[i] == LANCZOS_OK; f++)  // a strip of a host frame is contiguous: one call per frame
+                    rcs[i] = lanczos_resample_host(m->ctx[i], &dd, (const uint8_t*)in + (size_t)f * in_frame + (size_t)i0 * in_pitch,
+                                                   (uint8_t*)out + (size_t)f * out_frame + (size_t)r0 * out_pitch, 1);
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int i = 0; i < n; i++)
+        if (rcs[i] != LANCZOS_OK) return rcs[i];
+    return LANCZOS_OK;
+}
+
+#define LZM_HIP(call)                     \
+    do {                                  \
+        hipError_t e_ = (call);           \
+        if (e_ != hipSuccess) {           \
+            m->last_hip = (int)e_;        \
+            return LANCZOS_ERR_HIP;       \
+        }                                 \
+    } while (0)
+
+// Frames resident on the ROOT device (devices[0]) in, results on the root device out.  scatter (ncclSend/ncclRecv group) ->
+// every device resamples its share -> gather (second group).  Synchronous.  compute_ms / total_ms (optional): wall time of
+// the resample step alone (max over devices) and of the whole call.
+int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const void* d_in_root, void* d_out_root, int frames,
+                                int split, double* compute_ms, double* total_ms) {
+    if (!m || !d_in_root || !d_out_root || frames <= 0) return LANCZOS_ERR_BAD_ARG;
+    int rc = lanczos_validate(d);
+    if (rc != LANCZOS_OK) return rc;
+    if (split != LANCZOS_SPLIT_FRAMES && split != LANCZOS_SPLIT_ROWS) return LANCZOS_ERR_BAD_ARG;
+    if (d->out_rows != 0 && !(d->out_row0 == 0 && d->out_rows == d->out_h)) return LANCZOS_ERR_BAD_ARG;
+    const int n = (int)m->ctx.size();
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+            if (m->devices[i] == m->devices[j]) return LANCZOS_ERR_BAD_ARG;  // one rank per physical device
+    if (m->streams.empty()) {
+        m->streams.assign(n, nullptr);
+        m->d_in.assign(n, nullptr);
+        m->d_out.assign(n, nullptr);
+        m->d_in_bytes.assign(n, 0);
+        m->d_out_bytes.assign(n, 0);
+        for (int i = 0; i < n; i++) {
+            LZM_HIP(hipSetDevice(m->devices[i]));
+            LZM_HIP(hipStreamCreateWithFlags(&m->streams[i], hipStreamNonBlocking));
+        }
+    }
+    if (n > 1 && m->comms.empty()) {
+        if (!m->rccl.load()) return LANCZOS_ERR_UNSUPPORTED;  // no librccl on this system
+        m->comms.assign(n, nullptr);
+        if (m->rccl.CommInitAll(m->comms.data(), n, m->devices.data()) != 0) {
+            m->comms.clear();
+            return LANCZOS_ERR_HIP;
+        }
+    }
+    const size_t in_frame = lanczos_in_frame_bytes(d), out_frame = lanczos_out_frame_bytes(d);
+    const size_t in_pitch = (size_t)d->in_w * d->channels * d->bytes_per_sample;
+    const size_t out_pitch = (size_t)d->out_w * d->channels * d->bytes_per_sample;
+    // shares: frames -> (first frame, count); rows -> (out_row0, out_rows, in_row0, in_rows), the same strip of every frame
+    struct Share { int f0, cnt, r0, rows, i0, irows; size_t in_bytes, out_bytes; };
+    std::vector<Share> sh(n);
+    for (int i = 0; i < n; i++) {
+        Share& s = sh[i];
+        s = Share{0, frames, 0, d->out_h, 0, d->in_h, 0, 0};
+        if (split == LANCZOS_SPLIT_FRAMES) {
+            lanczos_partition_frames(frames, n, i, &s.f0, &s.cnt);
+            s.in_bytes = (size_t)s.cnt * in_frame;
+            s.out_bytes = (size_t)s.cnt * out_frame;
+        } else {
+            rc = lanczos_partition_rows(d, n, i, &s.r0, &s.rows, &s.i0, &s.irows);
+            if (rc != LANCZOS_OK) return rc;
+            s.in_bytes = (size_t)frames * s.irows * in_pitch;    // strip-major shard: [frame][strip rows]
+            s.out_bytes = (size_t)frames * s.rows * out_pitch;
+        }
+    }
+    for (int i = 1; i < n; i++) {  // peer shard buffers
+        LZM_HIP(hipSetDevice(m->devices[i]));
+        if (m->d_in_bytes[i] < sh[i].in_bytes) {
+            if (m->d_in[i]) (void)hipFree(m->d_in[i]);
+            m->d_in[i] = nullptr;
+            m->d_in_bytes[i] = 0;
+            LZM_HIP(hipMalloc(&m->d_in[i], sh[i].in_bytes ? sh[i].in_bytes : 16));
+            m->d_in_bytes[i] = sh[i].in_bytes;
+        }
+        if (m->d_out_bytes[i] < sh[i].out_bytes) {
+            if (m->d_out[i]) (void)hipFree(m->d_out[i]);
+            m->d_out[i] = nullptr;
+            m->d_out_bytes[i] = 0;
+            LZM_HIP(hipMalloc(&m->d_out[i], sh[i].out_bytes ? sh[i].out_bytes : 16));
+            m->d_out_bytes[i] = sh[i].out_bytes;
+        }
+    }
+    auto now_ms = []() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+    };
+    auto sync_all = [&]() -> int {
+        for (int i = 0; i < n; i++) {
+            LZM_HIP(hipSetDevice(m->devices[i]));
+            LZM_HIP(hipStreamSynchronize(m->streams[i]));
+        }
+        return LANCZOS_OK;
+    };
+    const double t_start = now_ms();
+    // ---- scatter: root sends every peer its input share (one send per contiguous piece), peers receive
+    if (n > 1) {
+        if (m->rccl.GroupStart() != 0) return LANCZOS_ERR_HIP;
+        for (int i = 1; i < n; i++) {
+            if (sh[i].in_bytes == 0) continue;
+            if (split == LANCZOS_SPLIT_FRAMES) {
+                m->rccl.Send((const uint8_t*)d_in_root + (size_t)sh[i].f0 * in_frame, sh[i].in_bytes, kNcclUint8, i, m->comms[0], m->streams[0]);
+                m->rccl.Recv(m->d_in[i], sh[i].in_bytes, kNcclUint8, 0, m->comms[i], m->streams[i]);
+            } else {
+                const size_t piece = (size_t)sh[i].irows * in_pitch;
+                for (int f = 0; f < frames; f++) {
+                    m->rccl.Send((const uint8_t*)d_in_root + (size_t)f * in_frame + (size_t)sh[i].i0 * in_pitch, piece, kNcclUint8, i, m->comms[0], m->streams[0]);
+                    m->rccl.Recv((uint8_t*)m->d_in[i] + (size_t)f * piece, piece, kNcclUint8, 0, m->comms[i], m->streams[i]);
+                }
+            }
+        }
+        if (m->rccl.GroupEnd() != 0) return LANCZOS_ERR_HIP;
+    }
+    if ((rc = sync_all()) != LANCZOS_OK) return rc;
+    const double t_c0 = now_ms();
+    // ---- compute: every device its share, on its own stream
+    for (int i = 0; i < n; i++) {
+        const Share& s = sh[i];
+        if (s.out_bytes == 0) continue;
+        lanczos_desc dd = *d;
+        dd.out_row0 = dd.out_rows = 0;
+        if (split == LANCZOS_SPLIT_FRAMES) {
+            const void* src = i == 0 ? (const void*)((const uint8_t*)d_in_root + (size_t)s.f0 * in_frame) : m->d_in[i];
+            void* dst = i == 0 ? (void*)((uint8_t*)d_out_root + (size_t)s.f0 * out_frame) : m->d_out[i];
+            rc = lanczos_resample_device(m->ctx[i], &dd, src, dst, s.cnt, 0, 0, m->streams[i]);
+        } else {
+            dd.out_row0 = s.r0;
+            dd.out_rows = s.rows;
+            if (i == 0)  // the root works in place on the full frames: frame strides are those of the whole frame
+                rc = lanczos_resample_device(m->ctx[0], &dd, (const uint8_t*)d_in_root + (size_t)s.i0 * in_pitch,
+                                             (uint8_t*)d_out_root + (size_t)s.r0 * out_pitch, frames, in_frame, out_frame, m->streams[0]);
+            else
+                rc = lanczos_resample_device(m->ctx[i], &dd, m->d_in[i], m->d_out[i], frames, 0, 0, m->streams[i]);
+        }
+        if (rc != LANCZOS_OK) return rc;
+    }
+    if ((rc = sync_all()) != LANCZOS_OK) return rc;
+    const double t_c1 = now_ms();
+    // ---- gather
+    if (n > 1) {
+        if (m->rccl.GroupStart() != 0) return LANCZOS_ERR_HIP;
+        for (int i = 1; i < n; i++) {
+            if (sh[i].out_bytes == 0) continue;
+            if (split == LANCZOS_SPLIT_FRAMES) {
+                m->rccl.Send(m->d_out[i], sh[i].out_bytes, kNcclUint8, 0, m->comms[i], m->streams[i]);
+                m->rccl.Recv((uint8_t*)d_out_root + (size_t)sh[i].f0 * out_frame, sh[i].out_bytes, kNcclUint8, i, m->comms[0], m->streams[0]);
+            } else {
+                const size_t piece = (size_t)sh[i].rows * out_pitch;
+                for (int f = 0; f < frames; f++) {
+                    m->rccl.Send((const uint8_t*)m->d_out[i] + (size_t)f * piece, piece, kNcclUint8, 0, m->comms[i], m->streams[i]);
+                    m->rccl.Recv((uint8_t*)d_out_root + (size_t)f * out_frame + (size_t)sh[i].r0 * out_pitch, piece, kNcclUint8, i, m->comms[0], m->streams[0]);
+                }
+            }
+        }
+        if (m->rccl.GroupEnd() != 0) return LANCZOS_ERR_HIP;
+    }
+    if ((rc = sync_all()) != LANCZOS_OK) return rc;
+    if (compute_ms) *compute_ms = t_c1 - t_c0;
+    if (total_ms) *total_ms = now_ms() - t_start;
+    return LANCZOS_OK;
+}
+
+}  // extern "C"

@@ -75,3 +75,24 @@ def test_harness_config1_end_to_end(tmp_path):
     diff = np.abs(observed.astype(int) - want.astype(int))
     assert observed.shape == want.shape and diff.max() <= 1
     assert abs(rms - float(np.sqrt((diff.astype(float) ** 2).mean()))) < 1e-3
+
+
+@pytest.mark.gpu
+def test_harness_multi_device_options(tmp_path):
+    """`--devices` path of the plain-C harness (lanczos_resample_multi_host): two contexts on device 0 stand in for two GPUs."""
+    _build()
+    img = P.gradient_noise(96, 128, 3)
+    want = O.expected_hwc_u8(O.cfg(128, 96, 256, 192, 3, 3, 2, 1), img)
+    src = tmp_path / "in.ppm"
+    _write_ppm(str(src), img)
+    for split in ("frames", "rows"):
+        dst = tmp_path / f"multi_{split}.png"
+        r = subprocess.run([os.path.join(PKG, "lanczos_upscale"), str(src), str(dst), "--exact", "--devices", "0,0",
+                            "--frames", "5", "--split", split], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"5 frames over 2 device(s), split by {split}" in r.stdout
+        assert np.array_equal(_read_png(str(dst)), want)
+    dst = tmp_path / "hls.png"                                         # --hls: the HLS-semantics mode through the harness
+    r = subprocess.run([os.path.join(PKG, "lanczos_upscale"), str(src), str(dst), "--hls"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(_read_png(str(dst)), O.hls_expected_hwc(O.cfg(128, 96, 256, 192, 3, 3, 2, 1), img))
