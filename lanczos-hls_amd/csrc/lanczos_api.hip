@@ -22,6 +22,7 @@
 #include "lanczos_march.hpp"
 #include "lanczos_generic.hpp"
 #include "lanczos_hls.hpp"
+#include "lanczos_rational.hpp"
 #include "lanczos_kernels_common.hpp"
 #include "lanczos_taps.hpp"
 
@@ -39,6 +40,11 @@ struct Plan {
     void* dev_block = nullptr;  // one allocation behind `dev`
     lz::FastConsts fast{};      // phase weights etc. for the specialised kernels
     bool fast_ok = false;
+    lz::RatHost rat;            // rational scales: per-index f32 weights, integer-phase flags (k_rat)
+    lz::RatTables rat_dev{};
+    lz::RatPHost ratp;          // exactly periodic rational scales: per-phase weights (k_ratp)
+    lz::RatTables ratp_dev{};
+    const float* ratp_w_dev = nullptr;
 };
 
 }  // namespace
@@ -115,7 +121,29 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
     size_t off_xw = off_vw + (size_t)d->out_h * taps * 8;
     size_t total = off_xw + (size_t)lz::kFastMaxS * lz::kMaxTaps * 8;
     p->fast_ok = !hls && lz::fast_prepare(*d, p->H, p->V, &p->fast);
+    if (!hls && d->scale_d != 1) lz::rat_prepare(*d, p->H, p->V, &p->rat);
+    size_t off_hwf = 0, off_vwf = 0, off_hint = 0, off_vint = 0;
+    if (p->rat.ok) {  // appended sections: f32 weights and integer-phase flags of both axes
+        off_hwf = total;
+        off_vwf = off_hwf + (size_t)d->out_w * taps * 4;
+        off_hint = off_vwf + (size_t)d->out_h * taps * 4;
+        off_vint = off_hint + (((size_t)d->out_w + 7) & ~(size_t)7);
+        total = off_vint + (((size_t)d->out_h + 7) & ~(size_t)7);
+    }
+    size_t off_pw = 0;
+    if (p->rat.ok && lz::ratp_has(*d)) lz::ratp_prepare(*d, p->H, p->V, p->rat, &p->ratp);
+    if (p->ratp.ok) {
+        off_pw = total;
+        total += sizeof(p->ratp.phase_w);
+    }
     std::vector<uint8_t> host(total, 0);
+    if (p->rat.ok) {
+        memcpy(host.data() + off_hwf, p->rat.h_wf.data(), p->rat.h_wf.size() * 4);
+        memcpy(host.data() + off_vwf, p->rat.v_wf.data(), p->rat.v_wf.size() * 4);
+        memcpy(host.data() + off_hint, p->rat.h_int.data(), p->rat.h_int.size());
+        memcpy(host.data() + off_vint, p->rat.v_int.data(), p->rat.v_int.size());
+    }
+    if (p->ratp.ok) memcpy(host.data() + off_pw, p->ratp.phase_w, sizeof(p->ratp.phase_w));
     if (p->fast_ok) {  // row 0: integer phase, row ph: phase ph
         memcpy(host.data() + off_xw, p->fast.wi, lz::kMaxTaps * 8);
         for (int ph = 1; ph < lz::kFastMaxS; ph++)
@@ -144,6 +172,24 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
     p->dev.h_w = (const double*)(b + off_hw);
     p->dev.v_w = (const double*)(b + off_vw);
     p->dev.x_w = (const double*)(b + off_xw);
+    if (p->rat.ok) {
+        p->rat_dev.h_wf = (const float*)(b + off_hwf);
+        p->rat_dev.v_wf = (const float*)(b + off_vwf);
+        p->rat_dev.h_int = b + off_hint;
+        p->rat_dev.v_int = b + off_vint;
+        p->rat_dev.bias = p->rat.bias;
+        p->rat_dev.vbias_rne = p->rat.vbias_rne;
+        p->rat_dev.near2 = p->rat.near2;
+        p->rat_dev.vlim = p->rat.vlim;
+        p->rat_dev.tight = p->rat.tight;
+    }
+    if (p->ratp.ok) {
+        p->ratp_dev = p->rat_dev;
+        p->ratp_dev.bias = p->ratp.bias;
+        p->ratp_dev.vbias_rne = p->ratp.vbias_rne;
+        p->ratp_dev.near2 = p->ratp.near2;
+        p->ratp_w_dev = (const float*)(b + off_pw);
+    }
     ctx->plans[key] = p;
     *out = p;
     return LANCZOS_OK;
@@ -538,7 +584,8 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
     bool prefix_fused = false;
     bool use_fast = p->fast_ok && ctx->force != LANCZOS_KERNEL_GENERIC &&
                     lz::fast_supports(*d, g);
-    if (ctx->force == LANCZOS_KERNEL_FAST && !use_fast) return LANCZOS_ERR_UNSUPPORTED;
+    const bool use_rat = !use_fast && p->rat.ok && ctx->force != LANCZOS_KERNEL_GENERIC && lz::rat_supports(*d, g);
+    if (ctx->force == LANCZOS_KERNEL_FAST && !use_fast && !use_rat) return LANCZOS_ERR_UNSUPPORTED;
 
     // Events are reserved only once nothing but a HIP failure can stop the call; a triple is committed (ev_used += 3)
     // after all three records succeeded, so timing_flush never meets an unrecorded event.
@@ -598,6 +645,36 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
             ctx->last_hip = (int)e;
             return LANCZOS_ERR_HIP;
         }
+        ctx->last_kernel = LANCZOS_KERNEL_FAST;
+    } else if (use_rat && p->ratp.ok && !(getenv("LANCZOS_NO_RATP") && atoi(getenv("LANCZOS_NO_RATP")) != 0)) {
+        hipError_t e = lz::ratp_launch(*d, g, p->dev, p->ratp_dev, p->ratp_w_dev, stream);
+        if (e != hipSuccess) {
+            ctx->last_hip = (int)e;
+            return LANCZOS_ERR_HIP;
+        }
+        ctx->last_kernel = LANCZOS_KERNEL_FAST;
+    } else if (use_rat) {
+        const int row_bytes = d->out_w * d->channels * d->bytes_per_sample;
+        const int tiles_x = (row_bytes + lz::kRatTileRowBytes - 1) / lz::kRatTileRowBytes;
+        const int tiles_y = (rows + lz::kRatTileH - 1) / lz::kRatTileH;
+        dim3 grid(tiles_x * tiles_y, frames);
+        const bool ex = d->mode == LANCZOS_MODE_EXACT;
+#define LZ_RAT(T, TAPS)                                                                                                  \
+    do {                                                                                                                 \
+        if (ex) hipLaunchKernelGGL((lz::k_rat<T, TAPS, true>), grid, dim3(lz::kRatThreads), 0, stream, g, p->dev, p->rat_dev);  \
+        else hipLaunchKernelGGL((lz::k_rat<T, TAPS, false>), grid, dim3(lz::kRatThreads), 0, stream, g, p->dev, p->rat_dev);    \
+    } while (0)
+        if (d->bytes_per_sample == 1) {
+            if (d->a == 2) LZ_RAT(uint8_t, 4);
+            else if (d->a == 3) LZ_RAT(uint8_t, 6);
+            else LZ_RAT(uint8_t, 8);
+        } else {
+            if (d->a == 2) LZ_RAT(uint16_t, 4);
+            else if (d->a == 3) LZ_RAT(uint16_t, 6);
+            else LZ_RAT(uint16_t, 8);
+        }
+#undef LZ_RAT
+        LZ_HIP(ctx, hipGetLastError());
         ctx->last_kernel = LANCZOS_KERNEL_FAST;
     } else {
         const int samples_w = d->out_w * d->channels;

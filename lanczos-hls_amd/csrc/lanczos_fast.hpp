@@ -545,23 +545,8 @@ inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTap
     }
     fc->vlim = integer_phase_flip_limit(fc->wi, a, (int)maxv);
     if (fc->vlim >= (d.bytes_per_sample == 1 ? 126 : 32766)) return false;  // SWAR test needs vlim < half range
-    // Tight filter precondition.  Lower-bound chain (integer_phase_flip_limit): v0 can only be left through a
-    // negative tiny term n*|w| reaching half the spacing below v0, which is >= 2^-54 * v0.  If the negative taps
-    // are exactly d = +2 and d = -2 with |w| < 2^-55, then n <= 2*v0 gives n*|w| < 2^-54 * v0: v0 stays.
-    {
-        bool ok = a >= 3;
-        const double negl = std::ldexp(1.0, -70) / maxv;  // contributes < 2^-70: cannot reach any half spacing >= 2^-54
-        for (int k = 0; k < taps && ok; k++) {
-            const int dist = a - 1 - k;                    // x - i of this tap
-            const double w = fc->wi[k];
-            if (dist == 2 || dist == -2) {
-                if (!(w < 0 && -w < std::ldexp(1.0, -55) * (1.0 - 1e-9))) ok = false;
-            } else if (w < 0 && -w > negl) {
-                ok = false;
-            }
-        }
-        fc->tight = ok ? 1 : 0;
-    }
+    // Tight filter precondition (integer_phase_tight, lanczos_taps.cpp)
+    fc->tight = integer_phase_tight(fc->wi, a, maxv) ? 1 : 0;
     // Integer-phase chain, last tap (x - i = -a): by then the running sum is v0 +- a few ulp >= 0.5, so its spacing is
     // >= 2^-54; a term below 2^-55 cannot move it (strictly less than half the spacing: no tie either).  The centre
     // weight is exactly 1.0 (sinc(0)*sinc(0)), so that product is the sample itself.

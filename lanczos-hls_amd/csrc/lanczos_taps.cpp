@@ -141,6 +141,25 @@ double f32_chain_error_bound(const double* w, int ntaps, double maxv) {
     return 1.02 * (err + wq);  // 2 % slack
 }
 
+bool integer_phase_tight(const double* wi, int a, double maxv) {
+    // Lower-bound chain (integer_phase_flip_limit): v0 can only be left through a negative tiny term n*|w| reaching half
+    // the spacing below v0, which is >= 2^-54 * v0.  If the negative taps are exactly d = +2 and d = -2 with |w| < 2^-55,
+    // then n <= 2*v0 gives n*|w| < 2^-54 * v0: v0 stays.
+    bool ok = a >= 3;
+    const int taps = 2 * a;
+    const double negl = std::ldexp(1.0, -70) / maxv;  // contributes < 2^-70: cannot reach any half spacing >= 2^-54
+    for (int k = 0; k < taps && ok; k++) {
+        const int dist = a - 1 - k;                    // x - i of this tap
+        const double w = wi[k];
+        if (dist == 2 || dist == -2) {
+            if (!(w < 0 && -w < std::ldexp(1.0, -55) * (1.0 - 1e-9))) ok = false;
+        } else if (w < 0 && -w > negl) {
+            ok = false;
+        }
+    }
+    return ok;
+}
+
 int integer_phase_flip_limit(const double* wi, int a, int maxv) {
     // Lower-bound chain (rounding is monotone): drop the positive tiny terms.  The negative terms in
     // front of the centre accumulate to -nb; each negative term behind it is applied on its own.  If

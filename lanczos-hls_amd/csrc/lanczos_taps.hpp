@@ -60,5 +60,9 @@ double f32_chain_error_bound_ordered(const double* w, const int* order, int n, d
 // Largest centre sample v0 for which the integer-phase double chain can still end below v0
 // (SURVEY.md Q4); every v0 above it provably comes out unchanged.  wi[k] = L(a-1-k), k = 0..2a-1.
 int integer_phase_flip_limit(const double* wi, int a, int maxv);
+// Tight-filter precondition on the integer-phase weights wi[k] = L(a-1-k): the only non-negligible negative taps sit at
+// +-2 samples and are < 2^-55 in magnitude.  Then a centre sample v0 whose +-2 neighbours are both <= 2*v0 provably
+// survives the double chain (the negative excursion stays below half the spacing under v0).
+bool integer_phase_tight(const double* wi, int a, double maxv);
 
 }  // namespace lz

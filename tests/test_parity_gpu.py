@@ -116,8 +116,73 @@ def test_oracle_parity_medium(ctx, pattern, mode):
         want = _oracle(img, sn, sd, a)
         got = ctx.resample(img, sn, sd, a, mode)
         _cmp(got, want, mode, f"{pattern} {w}x{h}x{c} {sn}/{sd} a={a}")
-        want_family = L.KERNEL_FAST if (w, h, c, sn, sd, a) in FAST_SHAPES else L.KERNEL_GENERIC
+        fast = (w, h, c, sn, sd, a) in FAST_SHAPES
+        if sd != 1:   # rational scales: the f32 tile kernel k_rat whenever the output rows are dword multiples
+            fast = (w * sn // sd * c) % 4 == 0
+        want_family = L.KERNEL_FAST if fast else L.KERNEL_GENERIC
         assert ctx.last_kernel() == want_family, (w, h, c, sn, sd, a, ctx.last_kernel())
+
+
+RATIONAL_SHAPES = [
+    # (in_w, in_h, channels, sn, sd, a) -- output rows are dword multiples: served by k_rat
+    (300, 200, 3, 4, 3, 3), (256, 120, 3, 3, 2, 3), (400, 90, 4, 3, 2, 2), (128, 77, 1, 5, 2, 4), (240, 131, 3, 5, 3, 3),
+    (96, 64, 4, 7, 4, 4), (12, 9, 4, 4, 3, 3), (64, 300, 1, 3, 2, 3), (1200, 40, 3, 4, 3, 3), (12, 5, 3, 4, 3, 2),
+]
+
+
+@pytest.mark.parametrize("mode", [L.MODE_EXACT, L.MODE_LSB1])
+@pytest.mark.parametrize("pattern", ["noise", "dark", "gradient", "blocks"])
+def test_rational_scales_fast_kernel(ctx, pattern, mode):
+    """4/3, 3/2, 5/2, 5/3, 7/4: the reference reduces SCALE_N/SCALE_D with gcd (lanczos.h:108-114) and evaluates
+    x = xx / SCALE in double; the f32 tile kernel follows its per-index taps."""
+    for (w, h, c, sn, sd, a) in RATIONAL_SHAPES:
+        img = P.ALL_U8[pattern](h, w, c)
+        want = _oracle(img, sn, sd, a)
+        got = ctx.resample(img, sn, sd, a, mode)
+        _cmp(got, want, mode, f"{pattern} {w}x{h}x{c} {sn}/{sd} a={a}")
+        assert ctx.last_kernel() == L.KERNEL_FAST, (w, h, c, sn, sd, a)
+    img16 = P.noise(60, 96, 4, seed=77, dtype=np.uint16)
+    got = ctx.resample(img16, 3, 2, 3, mode)
+    _cmp(got, _oracle(img16, 3, 2, 3), mode, "u16 3/2")
+    assert ctx.last_kernel() == L.KERNEL_FAST
+
+
+def test_rational_fast_kernel_known_answer_and_speed(ctx):
+    """SURVEY.md 8(c)'s 300x200 -> 400x266 (4/3) digest through the fast kernel, and the fast kernel against the f64
+    generic kernel on a 4/3 and a 3/2 frame batch.  Measured (profiles/README.md, round 2): 4.6x at 4/3, 5.1-5.3x at 3/2,
+    6.2x at 5/2; the asserted floors leave room for box-to-box spread."""
+    import time
+    import torch
+    with open(os.path.join(GOLD, "kat_digests.json")) as f:
+        kat = json.load(f)
+    planar = O.lcg_u8(3 * 200 * 300, 12345).reshape(3, 200, 300)
+    got = ctx.resample(np.ascontiguousarray(planar.transpose(1, 2, 0)), 4, 3, 3, L.MODE_EXACT)
+    assert ctx.last_kernel() == L.KERNEL_FAST
+    assert f"{O.fnv1a64(np.ascontiguousarray(got.transpose(2, 0, 1))):016x}" == kat["survey_8c"]["300x200_400x266_4-3_a3_c3"]
+    for (sn, sd) in ((4, 3), (3, 2)):
+        d = L.make_desc(1920, 1080, 3, sn, sd, 3)
+        x = torch.from_numpy(np.stack([P.gradient_noise(1080, 1920, 3, seed=40 + i) for i in range(4)])).cuda()
+        y = torch.empty((4, d.out_h, d.out_w, 3), dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        times = {}
+        outs = {}
+        for fam in (L.KERNEL_GENERIC, L.KERNEL_NONE):
+            ctx.force_kernel(fam)
+            for _ in range(3):
+                ctx.resample_device(d, x.data_ptr(), y.data_ptr(), 4, 0, 0, stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                ctx.resample_device(d, x.data_ptr(), y.data_ptr(), 4, 0, 0, stream)
+            torch.cuda.synchronize()
+            times[fam] = (time.perf_counter() - t0) / 10
+            outs[fam] = y.clone()
+        ctx.force_kernel(L.KERNEL_NONE)
+        assert ctx.last_kernel() == L.KERNEL_FAST
+        diff = (outs[L.KERNEL_GENERIC].to(torch.int16) - outs[L.KERNEL_NONE].to(torch.int16)).abs()
+        assert int(diff.max()) <= 1                                   # LSB1 against the always-exact kernel
+        print(f"rational {sn}/{sd}: generic {times[L.KERNEL_GENERIC] * 1e6:.1f} us, fast {times[L.KERNEL_NONE] * 1e6:.1f} us per 4 frames")
+        assert times[L.KERNEL_GENERIC] / times[L.KERNEL_NONE] >= (4.0 if (sn, sd) == (4, 3) else 4.6), (sn, sd, times)
 
 
 def test_tiny_images_all_taps_clipped(ctx):
