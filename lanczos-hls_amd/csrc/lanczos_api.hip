@@ -693,9 +693,13 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
     if (prefix_side) LZ_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));  // join
     if (has_prefix && !prefix_fused && !prefix_side && !prefix_same) {
         const int samples_w = d->out_w * d->channels;
-        dim3 grid((samples_w + 127) / 128, frames);
+        // columns per block: the row arrays (M + M2 rows) must fit 60 KB of LDS; deep prefixes (scales close to 1) get fewer
+        int bw = 128;
+        while (bw > 8 && (size_t)(p->prefix.M + p->prefix.M2) * bw * d->bytes_per_sample > 60 * 1024) bw >>= 1;
+        if ((size_t)(p->prefix.M + p->prefix.M2) * bw * d->bytes_per_sample > 60 * 1024) return LANCZOS_ERR_UNSUPPORTED;
+        dim3 grid((samples_w + bw - 1) / bw, frames);
 #define LZ_PREFIX(T, TAPS)                                                                                       \
-    hipLaunchKernelGGL((lz::k_prefix<T, TAPS>), grid, dim3(128), (size_t)(p->prefix.M + p->prefix.M2) * 128 * sizeof(T), stream, g, \
+    hipLaunchKernelGGL((lz::k_prefix<T, TAPS>), grid, dim3(bw), (size_t)(p->prefix.M + p->prefix.M2) * bw * sizeof(T), stream, g, \
                        p->dev, p->prefix.K, p->prefix.M, p->prefix.M2)
         if (d->bytes_per_sample == 1) {
             if (d->a == 2) LZ_PREFIX(uint8_t, 4);

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kGenTileW) void k_generic(FrameGeom g, TapTables t)
 // pi.M / pi.M2 <= kMaxPrefixRows + kMaxTaps are checked on the host.  TAPS is a template parameter so the
 // tap loops unroll and the H-pass loads of a row are all in flight together.
 template <typename T, int TAPS>
-__global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K, int M, int M2) {
+__global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K, int M, int M2) {  // blockDim.x <= 128
     const int C = g.channels;
     const int samples_w = g.out_w * C;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,9 +113,11 @@ __global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K,
     // H-pass rows 0..M2-1 and output rows 0..M-1 of this column.  In LDS, not in per-thread arrays: the recurrence
     // indexes them with run-time row numbers, and a register array indexed that way lands in scratch memory
     // (the first version of this kernel: 146 VGPRs + 160 B of scratch per lane).
-    extern __shared__ __attribute__((aligned(16))) uint8_t prefix_smem[];  // (M2 + M) rows of 128 samples
-    T(*hs)[128] = (T(*)[128])prefix_smem;
-    T(*os)[128] = hs + M2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t prefix_smem[];  // (M2 + M) rows of blockDim.x samples
+    const int bw = blockDim.x;   // 128 for the shallow prefixes of the usual scales; fewer columns per block for scales close
+                                 // to 1, whose prefix is hundreds of rows deep (K ~ a*S/(S-1))
+    T* hs = (T*)prefix_smem;     // [M2][bw]
+    T* os = hs + (size_t)M2 * bw; // [M][bw]
     const int tl = threadIdx.x;
 
     {   // horizontal pass of the rows the prefix reads (full_TB.h:55-65)
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K,
             double sum = 0;
 #pragma unroll
             for (int k = 0; k < TAPS; k++) sum += (double)v[k] * w[k];
-            hs[r][tl] = store_convert<T>(sum);
+            hs[r * bw + tl] = store_convert<T>(sum);
         }
     }
     // full_TB.h:69-76, xx descending: a tap at row i > xx sees the value already written there
@@ -151,15 +153,15 @@ __global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K,
         for (int k = 0; k < TAPS; k++) {
             int i = first + k;
             i = i < 0 ? 0 : (i > g.in_h - 1 ? g.in_h - 1 : i);  // weight 0 outside
-            const T v = i > xx ? os[i][tl] : hs[i][tl];
+            const T v = i > xx ? os[i * bw + tl] : hs[i * bw + tl];
             sum += (double)v * wv[k];
         }
-        os[xx][tl] = store_convert<T>(sum);
+        os[xx * bw + tl] = store_convert<T>(sum);
     }
     for (int xx = 0; xx < K; xx++) {
         if (xx < g.out_row0 || xx >= g.out_row0 + g.out_rows) continue;
         T* orow = (T*)(out_f + (size_t)(xx - g.out_row0) * g.out_pitch);
-        orow[j] = os[xx][tl];
+        orow[j] = os[xx * bw + tl];
     }
 }
 

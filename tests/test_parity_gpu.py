@@ -185,6 +185,22 @@ def test_rational_fast_kernel_known_answer_and_speed(ctx):
         assert times[L.KERNEL_GENERIC] / times[L.KERNEL_NONE] >= (4.0 if (sn, sd) == (4, 3) else 4.6), (sn, sd, times)
 
 
+def test_scales_close_to_one_deep_inplace_prefix(ctx):
+    """S -> 1: the in-place vertical pass (full_TB.h:67-77) reads already-written rows for K ~ a*S/(S-1) output rows --
+    27 rows at 9/8, 99 at 33/32, 195 at 65/64 (the cap of round 1 was 64).  Reduced N/D as lanczos.h:108-114 makes them."""
+    for (w, h, c, sn, sd, a) in [(128, 96, 3, 9, 8, 3), (128, 160, 3, 33, 32, 3), (64, 256, 1, 65, 64, 3), (64, 192, 4, 17, 16, 4)]:
+        img = P.noise(h, w, c, seed=31)
+        d = L.make_desc(w, h, c, sn, sd, a)
+        K = L.inplace_rows(d)
+        assert K == (a - 1) * sn // (sn - sd) + 1
+        want = _oracle(img, sn, sd, a)
+        for mode in (L.MODE_EXACT, L.MODE_LSB1):
+            _cmp(ctx.resample(img, sn, sd, a, mode), want, mode, f"deep prefix {sn}/{sd} K={K}")
+    with pytest.raises(L.LanczosError) as e:       # S = 1 (and below): refused, see DESIGN.md
+        ctx.resample(P.noise(16, 16, 3), 4, 4, 3)
+    assert e.value.code == L.ERR_UNSUPPORTED
+
+
 def test_tiny_images_all_taps_clipped(ctx):
     """Images narrower/shorter than the 2a tap window: every loop bound of full_TB.h:59,72 clips."""
     rng = np.random.default_rng(11)
