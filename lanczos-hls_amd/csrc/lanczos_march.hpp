@@ -137,10 +137,14 @@ struct MarchCfg {
     static constexpr int LDS_WL = NLISTS * WLW * 2;
     static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL;
     static constexpr int NNI = F::UNIT_OUT_S - P * C;                // non-integer-phase samples of a unit
-#ifdef LZ_MARCH_NO_LDSDMA
-    static constexpr bool LDSDMA = false;
+    // LDS-DMA for the input rows (buffer_load_dwordx4 ... lds, no staging VGPRs, counted vmcnt wait): opt-in.  Measured in
+    // round 2 (interleaved A/B): config 2 108.3 us with register staging vs 110.3 with LDS-DMA, config 5 613 vs 691 --
+    // the tile image of a 512-thread workgroup is 2 x 16 KiB of which a third is padding lanes, and the DMA has only the
+    // V pass to land in.  The role-split shape (LZ_MARCH_SPLIT) needs it (its H waves have no registers to spare).
+#if defined(LZ_MARCH_LDSDMA) || defined(LZ_MARCH_SPLIT)
+    static constexpr bool LDSDMA = true;
 #else
-    static constexpr bool LDSDMA = true;   // input rows go HBM -> LDS directly (buffer_load_dwordx4 ... lds), no staging VGPRs
+    static constexpr bool LDSDMA = false;
 #endif
     // S = 2: the half-phase weights are symmetric (L is even and x = m + 1/2 exactly), so a chain is 3 exact pair sums and
     // 3 fmafs -- the same 6 instructions, half the rounding steps: eps (and with it the near-integer fix-up rate) halves
@@ -148,6 +152,13 @@ struct MarchCfg {
     static constexpr bool SYM = false;
 #else
     static constexpr bool SYM = S == 2;
+#endif
+    // H pass, u8: the chain carries eps - 0.5 and the RNE byte convert is the truncating store (4-op near-integer test)
+    // (only where measured faster: with the paired chains of S = 2; at S = 3 the same change cost 30 % -- 200 vs 153 us)
+#ifdef LZ_MARCH_OLD_NEAR
+    static constexpr bool RNE_H = false;
+#else
+    static constexpr bool RNE_H = SB == 1 && SYM;
 #endif
     // register budget (2nd launch bound = waves per SIMD the compiler must leave room for).  SPLIT: 4 workgroups x 6 waves
     // = 24 waves per CU = 6 per SIMD -> 80 VGPRs; the others keep the compiler's own choice (72 for config 2 in round 1)
@@ -343,7 +354,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     const uint32_t addc1 = (uint32_t)fc.vlim < HALF - 1 ? HALF - 1 - (uint32_t)fc.vlim : 0;
     // the chain bias and the SWAR masks live in VGPRs for the same reason (a literal is a constant-bus read too)
     // SB == 1: the H chain carries eps - 0.5 (see the byte convert in hpass); SYM: the paired chain's (smaller) eps
-    float hbias = SB == 1 ? (K::SYM ? fc.vbias_rne_p : fc.vbias_rne) : (K::SYM ? fc.bias_p : fc.bias);
+    float hbias = K::RNE_H ? (K::SYM ? fc.vbias_rne_p : fc.vbias_rne) : (K::SYM ? fc.bias_p : fc.bias);
     const float near2 = K::SYM ? fc.near2_p : fc.near2;
     constexpr uint32_t LOW = SB == 1 ? 0x7f7f7f7fu : 0x7fff7fffu;
     constexpr uint32_t TOP = SB == 1 ? 0x80808080u : 0x80008000u;
@@ -447,7 +458,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         }
                     }
                     const int o = q * C + c;
-                    if (SB == 1) {
+                    if (K::RNE_H) {
                         // acc = sum + (eps - 0.5) + chain error, |chain error| < eps: the saturating round-to-nearest-even
                         // byte convert is floor(sum + eps') with eps' in (0, 2 eps) -- the reference's truncating store --
                         // unless sum lies within 2 eps below an integer, i.e. fract(acc) in [0.5, 0.5 + 2 eps): undecided.
@@ -464,12 +475,13 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, F::MAXV + 0.5f);
                         const float fl = __builtin_floorf(xc);
                         dmin = __builtin_fminf(dmin, xc - fl);
-                        ow[o / 2] |= (unsigned)fl << (16 * (o % 2));
+                        if (SB == 1) ow[o / 4] = __builtin_amdgcn_cvt_pk_u8_f32(fl, o % 4, ow[o / 4]);
+                        else ow[o / 2] |= (unsigned)fl << (16 * (o % 2));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            near = SB == 1 ? dminu < __builtin_bit_cast(uint32_t, near2) : dmin < near2;
+            near = K::RNE_H ? dminu < __builtin_bit_cast(uint32_t, near2) : dmin < near2;
             // widest aligned LDS stores the unit allows
             if (F::UNIT_OUT_DW % 2 == 0) {
 #pragma unroll
