@@ -75,8 +75,12 @@ struct MarchShape {
     static constexpr int P = 0, UPR = 0;                            // unit geometry: FastCfg's default
 };
 template <int A>
-struct MarchShape<uint8_t, 3, 3, A> {  // 288 dword columns: one V group of 4.5 waves
+struct MarchShape<uint8_t, 3, 3, A> {  // 288 dword columns = 4.5 waves per V group (padded to 5)
+#ifdef LZ_MARCH_C3_NGRP2
+    static constexpr int NGRP = 2;     // 10-wave workgroups: every thread has V work (the V pass is 2/3 of this configuration)
+#else
     static constexpr int NGRP = 1;
+#endif
     static constexpr int MS = 12;
     static constexpr bool SPLIT = false;
     static constexpr int P = 0, UPR = 0;
@@ -119,7 +123,16 @@ struct MarchCfg {
     static constexpr int NHW = SPLIT ? (NU + 63) / 64 : 0;           // SPLIT: waves [0, NHW) are H waves
     static constexpr int NT = SPLIT ? NHW * 64 + ((NT_V + 63) / 64) * 64 : (((NT_V > NU ? NT_V : NU) + 63) / 64) * 64;
     static constexpr int NWAVES = NT / 64;
-    static constexpr int RS = (2 * MS + TAPS - 1) <= 32 ? 32 : 64;   // ring rows: two ticks + the window
+    // ring rows: two ticks + the window.  A power of two where 32 rows do (index = row & 31); otherwise the next multiple of
+    // 8 and a modulo -- at a = 4 that is 40 rows instead of 64: 24 KiB less LDS, two resident workgroups instead of one
+#ifdef LZ_MARCH_RING_POW2
+    static constexpr int RS = (2 * MS + TAPS - 1) <= 32 ? 32 : 64;
+#else
+    static constexpr int RS = (2 * MS + TAPS - 1) <= 32 ? 32 : ((2 * MS + TAPS - 1 + 7) / 8) * 8;
+#endif
+    static constexpr bool RS_POW2 = (RS & (RS - 1)) == 0;
+    // slot of ring row `rel` = row - hb (>= -RS: the first ticks read rows above the chunk, whose results are never stored)
+    static __device__ __forceinline__ int ring_slot(int rel) { return RS_POW2 ? (rel & (RS - 1)) : (rel + RS) % RS; }
     static constexpr int IN_PITCH = F::IN_PITCH, H_PITCH = F::H_PITCH, CPR = F::CPR;
     static constexpr int NCH = MS * CPR;                             // 16-byte chunks of one tick's input
     static constexpr int NLT = SPLIT ? NHW * 64 : NT;                // threads that move the input rows (SPLIT: the H
@@ -131,7 +144,7 @@ struct MarchCfg {
     // measured 13 % SLOWER, interleaved A/B on one device: the extra 7 KiB of LDS costs residency.)
     static constexpr int WL_ROUND = 64 * F::UNIT_IN_DW;               // most entries one round can add
     static constexpr int WLW = WL_ROUND + 128;                        // sparse flags: all rounds share ONE dense pass
-    static constexpr int NLISTS = SPLIT ? NHW : NWAVES;               // only waves that run the H pass keep a list
+    static constexpr int NLISTS = SPLIT ? NHW : (NU + 63) / 64;       // only waves that run the H pass keep a list
     static constexpr int LDS_TIN = 2 * TIN_BYTES;                    // double buffered
     static constexpr int LDS_HBUF = RS * H_PITCH;
     static constexpr int LDS_WL = NLISTS * WLW * 2;
@@ -160,12 +173,27 @@ struct MarchCfg {
 #else
     static constexpr bool RNE_H = SB == 1 && SYM;
 #endif
+#ifdef LZ_MARCH_NO_PK16
+    static constexpr bool PK16 = false;
+#else
+    static constexpr bool PK16 = true;   // 16-bit samples: truncating convert + unsigned min instead of med3 + floor
+#endif
     // register budget (2nd launch bound = waves per SIMD the compiler must leave room for).  SPLIT: 4 workgroups x 6 waves
     // = 24 waves per CU = 6 per SIMD -> 80 VGPRs; the others keep the compiler's own choice (72 for config 2 in round 1)
 #ifndef LZ_MARCH_MIN_WAVES
 #define LZ_MARCH_MIN_WAVES 6
 #endif
-    static constexpr int MIN_WAVES = SPLIT ? LZ_MARCH_MIN_WAVES : 1;
+#ifndef LZ_MARCH_C3_MINW
+#define LZ_MARCH_C3_MINW 1
+#endif
+    // per-lane indices rebuilt every tick from an opaque copy of the thread id instead of living in registers across the
+    // phases (what the RIDE variant does): configurations that sit just above an occupancy step
+#ifdef LZ_MARCH_C3_OPAQUE
+    static constexpr bool OPAQUE_IDX = SB == 1 && C == 3 && S == 3;
+#else
+    static constexpr bool OPAQUE_IDX = false;
+#endif
+    static constexpr int MIN_WAVES = SPLIT ? LZ_MARCH_MIN_WAVES : ((SB == 1 && C == 3 && S == 3) ? LZ_MARCH_C3_MINW : 1);
     static_assert(MS % NGRP == 0, "V groups split a tick evenly");
     static_assert(MRG * S <= 64, "the EXACT-mode redo mask has one bit per output row of a V group");
     static_assert(NGRP == 1 || NVT_PAD % 64 == 0, "V groups must be whole waves");
@@ -307,7 +335,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     // instead of being held in registers across the other phases: the kernel sits on its 72-VGPR budget.)
     auto issue_loads = [&](int tick) {
         int t1 = tid;
-        if (RIDE || STAMP || K::SPLIT) asm volatile("" : "+v"(t1));
+        if (RIDE || STAMP || K::SPLIT || K::OPAQUE_IDX) asm volatile("" : "+v"(t1));
 #pragma unroll
         for (int it = 0; it < K::LOAD_IT; it++) {
             const int idx = t1 + it * K::NLT;
@@ -366,7 +394,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         const uint8_t* tin = smem + (tick & 1) * K::TIN_BYTES;
         const int h0 = hb + tick * K::MS;           // first H row of the tick
         int t3 = tid;
-        if (RIDE || STAMP || K::SPLIT) asm volatile("" : "+v"(t3));
+        if (RIDE || STAMP || K::SPLIT || K::OPAQUE_IDX) asm volatile("" : "+v"(t3));
         const int row = t3 / K::UPR, u = t3 % K::UPR;
         const bool unit_ok = t3 < K::NU && h0 + row <= h_last && !LZ_DBG(g, 1);
         uint32_t im = 0;      // undecided integer-phase samples: bit (8*e*SB + i) <-> own input sample i*VEC + e
@@ -381,7 +409,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
             // from <= 2 window dwords); the computed samples are inserted as they are produced.  One CHANNEL at a
             // time, fenced, so that only WIN_PX converted samples are live at once (registers, not ILP, are scarce:
             // <= 64 VGPRs lets every SIMD hold 8 waves, which is what makes 4 workgroups per CU always placeable).
-            const int slot = (h0 + row - hb) & (K::RS - 1);
+            const int slot = K::ring_slot(h0 + row - hb);
             uint32_t* hp = (uint32_t*)hbuf + slot * (K::H_PITCH / 4) + u * F::UNIT_OUT_DW;
             uint32_t ow[F::UNIT_OUT_DW];
 #pragma unroll
@@ -470,6 +498,15 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         const uint32_t gu = __builtin_bit_cast(uint32_t, g);
                         dminu = gu < dminu ? gu : dminu;
                         ow[o / 4] = __builtin_amdgcn_cvt_pk_u8_f32(acc, o % 4, ow[o / 4]);
+                    } else if (SB == 2 && K::PK16) {
+                        // 16-bit samples: acc = sum + eps.  Below 1/2 the store is 0 whatever the sum (and black regions, whose
+                        // sums are exactly 0, must not look "within eps of an integer"); the float -> u32 convert truncates
+                        // and an unsigned min saturates: 2.5 slow-class ops per sample instead of 4
+                        const float m = __builtin_fmaxf(acc, 0.5f);
+                        dmin = __builtin_fminf(dmin, __builtin_amdgcn_fractf(m));
+                        unsigned uv = (unsigned)m;                      // v_cvt_u32_f32: truncation
+                        uv = uv < 65535u ? uv : 65535u;
+                        ow[o / 2] |= uv << (16 * (o % 2));
                     } else {
                         // below 1 / above max the store clamps: nothing to decide there
                         const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, F::MAXV + 0.5f);
@@ -571,7 +608,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
 #pragma unroll
                         for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * w[k];
                     }
-                    const int slot = (h0 + erow - hb) & (K::RS - 1);
+                    const int slot = K::ring_slot(h0 + erow - hb);
                     hbufT[slot * (K::H_PITCH / SB) + xl * C + c] = store_convert<T>(sum);
                 }
                 cnt = 0;
@@ -632,7 +669,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     // other vector-memory instruction: the march loop then waits for its input prefetch with a counted vmcnt
     auto vpass = [&](int tick) -> bool {
         int t2 = K::SPLIT ? tid - K::NHW * 64 : tid;
-        if (RIDE || STAMP) asm volatile("" : "+v"(t2));
+        if (RIDE || STAMP || K::OPAQUE_IDX) asm volatile("" : "+v"(t2));
         const int grp = K::NGRP == 1 ? (t2 < K::NVT ? 0 : 1) : grp_w;
         const int col = t2 - grp * K::NVT_PAD;
         const unsigned col_b = (unsigned)(tx * F::TWB_OUT + col * 4);
@@ -651,7 +688,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                 if (K::SYM) asm volatile("" : "+v"(win[slot_i][e]));  // see hpass: no integer pair sums
             }
         };
-        auto ring = [&](int r) { return hcol[((r - hb) & (K::RS - 1)) * HP]; };  // H row r of this column
+        auto ring = [&](int r) { return hcol[K::ring_slot(r - hb) * HP]; };  // H row r of this column
         // rows m_g-a+1 .. m_g+a-1 seed the window; rows before hb were never produced: only read for m < m_b,
         // whose outputs are not stored
         if (!K::SPLIT) {
@@ -719,6 +756,10 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                             // an undecided sample, which is within 1 LSB either way)
 #pragma unroll
                             for (int e = 0; e < 4; e++) packed = __builtin_amdgcn_cvt_pk_u8_f32(accs[e], e, packed);
+                        } else if (SB == 2 && !EXACT && K::PK16) {
+                            // floor(sum + eps) clamped to [0, 65535]: max with 0, truncating convert, saturating pack
+                            const unsigned u0 = (unsigned)__builtin_fmaxf(accs[0], 0.0f), u1 = (unsigned)__builtin_fmaxf(accs[1], 0.0f);
+                            packed = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(u0, u1));
                         } else {
 #pragma unroll
                             for (int e = 0; e < F::VEC; e++) {

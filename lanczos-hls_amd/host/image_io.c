@@ -122,8 +122,10 @@ static uint8_t* load_png(const uint8_t* buf, size_t n, int* w, int* h, int* ch) 
         }
         pos += 12 + len;
     }
-    if (W <= 0 || H <= 0 || W > LZ_IMAGE_MAX_DIM || H > LZ_IMAGE_MAX_DIM || depth != 8 || interlace != 0 || !z) {
-        g_err = "unsupported PNG (need 8-bit, non-interlaced)";
+    const int depth_ok = depth == 8 || depth == 16 || ((depth == 1 || depth == 2 || depth == 4) && (ctype == 0 || ctype == 3));
+    if (W <= 0 || H <= 0 || W > LZ_IMAGE_MAX_DIM || H > LZ_IMAGE_MAX_DIM || !depth_ok || interlace > 1 || !z ||
+        (ctype == 3 && depth == 16)) {
+        g_err = "unsupported PNG (bit depth / interlace method)";
         free(z);
         return NULL;
     }
@@ -133,38 +135,68 @@ static uint8_t* load_png(const uint8_t* buf, size_t n, int* w, int* h, int* ch) 
         free(z);
         return NULL;
     }
-    size_t stride = (size_t)W * sc;
-    uLongf rawlen = (uLongf)((stride + 1) * H);
-    uint8_t* raw = (uint8_t*)malloc(rawlen);
-    if (!raw || uncompress(raw, &rawlen, z, (uLong)zlen) != Z_OK || rawlen != (stride + 1) * H) {
+    /* One pass (non-interlaced) or the seven Adam7 passes: each is a reduced image with its own filtered scanlines. */
+    static const int ax0[7] = {0, 4, 0, 2, 0, 1, 0}, ay0[7] = {0, 0, 4, 0, 2, 0, 1};
+    static const int adx[7] = {8, 8, 4, 4, 2, 2, 1}, ady[7] = {8, 8, 8, 4, 4, 2, 2};
+    const int npass = interlace ? 7 : 1;
+    const int bpp_bits = sc * depth;                  /* bits per pixel in the file */
+    const int fbpp = (bpp_bits + 7) / 8;              /* filter distance in bytes */
+    size_t rawlen_need = 0;
+    for (int p = 0; p < npass; p++) {
+        const int pw = interlace ? (W - ax0[p] + adx[p] - 1) / adx[p] : W, ph = interlace ? (H - ay0[p] + ady[p] - 1) / ady[p] : H;
+        if (pw > 0 && ph > 0) rawlen_need += ((size_t)((size_t)pw * bpp_bits + 7) / 8 + 1) * ph;
+    }
+    uLongf rawlen = (uLongf)rawlen_need;
+    uint8_t* raw = (uint8_t*)malloc(rawlen_need ? rawlen_need : 1);
+    if (!raw || uncompress(raw, &rawlen, z, (uLong)zlen) != Z_OK || rawlen != rawlen_need) {
         g_err = "PNG inflate failed";
         free(raw);
         free(z);
         return NULL;
     }
     free(z);
-    uint8_t* img = (uint8_t*)malloc(stride * H);
+    uint8_t* img = (uint8_t*)malloc((size_t)W * H * sc); /* 8 bits per sample: 16-bit files keep their high byte (stb) */
     if (!img) {
         free(raw);
         return NULL;
     }
-    for (int y = 0; y < H; y++) {
-        const uint8_t* s = raw + (stride + 1) * y;
-        uint8_t* d = img + stride * y;
-        const uint8_t* up = y ? d - stride : NULL;
-        int ft = s[0];
-        s++;
-        for (size_t x = 0; x < stride; x++) {
-            int a = x >= (size_t)sc ? d[x - sc] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)sc) ? up[x - sc] : 0;
-            int v = s[x];
-            switch (ft) {
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) >> 1; break;
-                case 4: v += paeth(a, b, c); break;
-                default: break;
+    size_t rpos = 0;
+    for (int p = 0; p < npass; p++) {
+        const int pw = interlace ? (W - ax0[p] + adx[p] - 1) / adx[p] : W, ph = interlace ? (H - ay0[p] + ady[p] - 1) / ady[p] : H;
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t rb = ((size_t)pw * bpp_bits + 7) / 8; /* bytes of one scanline of this pass */
+        uint8_t* prev = NULL;
+        for (int y = 0; y < ph; y++) {
+            uint8_t* line = raw + rpos;
+            const int ft = line[0];
+            line++;
+            for (size_t x = 0; x < rb; x++) { /* un-filter in place */
+                const int a = x >= (size_t)fbpp ? line[x - fbpp] : 0, b = prev ? prev[x] : 0, c = (prev && x >= (size_t)fbpp) ? prev[x - fbpp] : 0;
+                int v = line[x];
+                switch (ft) {
+                    case 1: v += a; break;
+                    case 2: v += b; break;
+                    case 3: v += (a + b) >> 1; break;
+                    case 4: v += paeth(a, b, c); break;
+                    default: break;
+                }
+                line[x] = (uint8_t)v;
             }
-            d[x] = (uint8_t)v;
+            const int oy = interlace ? ay0[p] + y * ady[p] : y;
+            for (int x = 0; x < pw; x++) {
+                const int ox = interlace ? ax0[p] + x * adx[p] : x;
+                uint8_t* d = img + ((size_t)oy * W + ox) * sc;
+                for (int k = 0; k < sc; k++) {
+                    if (depth == 8) d[k] = line[(size_t)x * sc + k];
+                    else if (depth == 16) d[k] = line[((size_t)x * sc + k) * 2];
+                    else { /* 1, 2, 4 bits: one channel; gray is scaled to 0..255, palette indices stay */
+                        const int bit = x * depth, v = (line[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+                        d[k] = (uint8_t)(ctype == 3 ? v : v * 255 / ((1 << depth) - 1));
+                    }
+                }
+            }
+            prev = line;
+            rpos += rb + 1;
         }
     }
     free(raw);
@@ -223,7 +255,106 @@ static uint8_t* load_pnm(const uint8_t* buf, size_t n, int* w, int* h, int* ch) 
     return img;
 }
 
+/* Windows BMP: BITMAPINFOHEADER and later, uncompressed 24 / 32 bits per pixel (BI_RGB, BI_BITFIELDS with byte-aligned
+ * masks) and 8-bit palettes; bottom-up or top-down. */
+static uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint8_t* load_bmp(const uint8_t* buf, size_t n, int* w, int* h, int* ch) {
+    if (n < 54 || buf[0] != 'B' || buf[1] != 'M') return NULL;
+    const uint32_t off = le32(buf + 10), hdr = le32(buf + 14);
+    if (hdr < 40 || 14 + (size_t)hdr > n) {
+        g_err = "unsupported BMP header";
+        return NULL;
+    }
+    const int32_t W = (int32_t)le32(buf + 18), Hs = (int32_t)le32(buf + 22);
+    const int bpp = buf[28] | (buf[29] << 8);
+    const uint32_t comp = le32(buf + 30);
+    const int H = Hs < 0 ? -Hs : Hs, flip = Hs > 0;
+    if (W <= 0 || H <= 0 || W > LZ_IMAGE_MAX_DIM || H > LZ_IMAGE_MAX_DIM || (bpp != 8 && bpp != 24 && bpp != 32) ||
+        (comp != 0 && !(comp == 3 && bpp == 32))) {
+        g_err = "unsupported BMP (need uncompressed 8 / 24 / 32 bpp)";
+        return NULL;
+    }
+    int shift[4] = {16, 8, 0, 24}; /* BGRA byte order as R, G, B, A shifts */
+    int has_alpha = 0;
+    if (comp == 3 && (size_t)14 + 40 + 12 <= n) {
+        for (int k = 0; k < 3 + (hdr >= 56); k++) {
+            const uint32_t m = le32(buf + 54 + 4 * k);
+            if (m != 0xffu && m != 0xff00u && m != 0xff0000u && m != 0xff000000u) {
+                if (k == 3 && m == 0) continue;
+                g_err = "unsupported BMP bit masks";
+                return NULL;
+            }
+            shift[k] = m == 0xffu ? 0 : m == 0xff00u ? 8 : m == 0xff0000u ? 16 : 24;
+            if (k == 3) has_alpha = 1;
+        }
+    }
+    const size_t stride = (((size_t)W * bpp + 31) / 32) * 4;
+    if (off > n || stride * H > n - off) {
+        g_err = "truncated BMP";
+        return NULL;
+    }
+    const uint8_t* pal = buf + 14 + hdr;
+    uint32_t ncol = le32(buf + 46);
+    if (bpp == 8) {
+        if (ncol == 0 || ncol > 256) ncol = 256;
+        if ((size_t)14 + hdr + 4 * (size_t)ncol > n) {
+            g_err = "truncated BMP palette";
+            return NULL;
+        }
+    }
+    const int sc = (bpp == 32 && has_alpha) ? 4 : 3;
+    uint8_t* img = (uint8_t*)malloc((size_t)W * H * sc);
+    if (!img) return NULL;
+    for (int y = 0; y < H; y++) {
+        const uint8_t* s = buf + off + stride * (size_t)(flip ? H - 1 - y : y);
+        uint8_t* d = img + (size_t)y * W * sc;
+        for (int x = 0; x < W; x++) {
+            if (bpp == 8) {
+                const uint8_t* e = pal + 4 * (s[x] < ncol ? s[x] : 0);
+                d[3 * x] = e[2];
+                d[3 * x + 1] = e[1];
+                d[3 * x + 2] = e[0];
+            } else if (bpp == 24) {
+                d[3 * x] = s[3 * x + 2];
+                d[3 * x + 1] = s[3 * x + 1];
+                d[3 * x + 2] = s[3 * x];
+            } else {
+                const uint32_t v = le32(s + 4 * x);
+                for (int k = 0; k < sc; k++) d[sc * x + k] = (uint8_t)(v >> shift[k]);
+            }
+        }
+    }
+    *w = W;
+    *h = H;
+    *ch = sc;
+    return img;
+}
+
+#ifdef LANCZOS_WITH_STB
+/* Built with -DLANCZOS_WITH_STB -I<directory holding stb_image.h / stb_image_write.h> (make harness_stb STB_DIR=...): the
+ * reference's own decoder and encoder (stb.cpp:1-6, full_TB.h:107,172) behind the same four functions -- every format
+ * stbi_load accepts, including JPEG.  The headers are NOT part of this repository; a maintainer who drops the library into
+ * the reference tree points STB_DIR at LanczosUpscaler/stb_image. */
+#define STBI_NO_SIMD
+#define STB_IMAGE_IMPLEMENTATION
+#include "stb_image.h"
+#define STB_IMAGE_WRITE_IMPLEMENTATION
+#include "stb_image_write.h"
+#endif
+
 uint8_t* lz_image_load(const char* path, int* w, int* h, int* channels_in_file, int desired_channels) {
+#ifdef LANCZOS_WITH_STB
+    int sw = 0, sh = 0, sc2 = 0;
+    uint8_t* p = stbi_load(path, &sw, &sh, &sc2, desired_channels);
+    if (!p) {
+        g_err = "stbi_load failed";
+        return NULL;
+    }
+    if (w) *w = sw;
+    if (h) *h = sh;
+    if (channels_in_file) *channels_in_file = sc2;
+    return p;
+#endif
     size_t n = 0;
     uint8_t* buf = read_file(path, &n);
     if (!buf) {
@@ -231,7 +362,9 @@ uint8_t* lz_image_load(const char* path, int* w, int* h, int* channels_in_file, 
         return NULL;
     }
     int W = 0, H = 0, sc = 0;
-    uint8_t* img = (n > 2 && buf[0] == 'P') ? load_pnm(buf, n, &W, &H, &sc) : load_png(buf, n, &W, &H, &sc);
+    uint8_t* img = (n > 2 && buf[0] == 'P') ? load_pnm(buf, n, &W, &H, &sc)
+                   : (n > 2 && buf[0] == 'B' && buf[1] == 'M') ? load_bmp(buf, n, &W, &H, &sc)
+                                                                : load_png(buf, n, &W, &H, &sc);
     free(buf);
     if (!img) return NULL;
     if (w) *w = W;
@@ -255,6 +388,9 @@ static void write_chunk(FILE* f, const char* type, const uint8_t* data, uint32_t
 }
 
 int lz_image_write_png(const char* path, int w, int h, int comp, const void* data, int stride_bytes) {
+#ifdef LANCZOS_WITH_STB
+    return stbi_write_png(path, w, h, comp, data, stride_bytes ? stride_bytes : w * comp);
+#endif
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     static const int ctype_of[5] = {0, 0, 4, 2, 6};
     if (w <= 0 || h <= 0 || comp < 1 || comp > 4 || !data) return 0;

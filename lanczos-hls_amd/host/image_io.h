@@ -4,8 +4,13 @@
  * The reference's harness uses stb_image / stb_image_write (stb.cpp, full_TB.h:107,172): stbi_load returns
  * interleaved u8 HWC with the requested channel count; stbi_write_png takes the same layout.  This is our own
  * small codec with the SAME buffer contract (so a caller that already links stb can keep using it and just
- * hand the buffers to lanczos_u8): PNG (8-bit gray / gray+alpha / RGB / RGBA, non-interlaced) through zlib,
- * and binary PPM/PGM.
+ * hand the buffers to lanczos_u8): PNG through zlib (1/2/4/8/16 bits per sample, gray / gray+alpha / RGB / RGBA / palette,
+ * Adam7 interlace; 16-bit samples keep their high byte, as stb does), BMP (uncompressed 8 / 24 / 32 bpp) and binary PPM/PGM.
+ * NOT decoded by the own codec: JPEG, GIF, PSD, TGA, HDR, PIC (stbi_load takes them).  For those -- or to run on exactly
+ * the reference's decoder -- build with the reference's stb headers where they lie: `make -C lanczos-hls_amd harness_stb
+ * STB_DIR=<reference>/LanczosUpscaler/stb_image` (-DLANCZOS_WITH_STB): the same four functions then call stbi_load /
+ * stbi_write_png (stb.cpp:1-6, full_TB.h:107,172).  The stb headers are third-party files of the reference tree and are not
+ * copied into this repository.
  */
 #ifndef LZ_IMAGE_IO_H
 #define LZ_IMAGE_IO_H
