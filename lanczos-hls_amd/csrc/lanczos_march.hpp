@@ -148,7 +148,15 @@ struct MarchCfg {
     static constexpr int LDS_TIN = 2 * TIN_BYTES;                    // double buffered
     static constexpr int LDS_HBUF = RS * H_PITCH;
     static constexpr int LDS_WL = NLISTS * WLW * 2;
-    static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL;
+    // scales whose per-index double weights are not the phase weights bit for bit (S = 3: x = xx / 3.0 is rounded) keep the
+    // strip's slice of the horizontal tap table in LDS: a fix-up that gathers 6 doubles from global memory holds its
+    // workgroup's barrier for a memory round trip (measured on config 3: near-integer fix-ups 33 of 158 us)
+#ifdef LZ_MARCH_NO_HW_LDS
+    static constexpr int LDS_HW = 0;
+#else
+    static constexpr int LDS_HW = (S == 3) ? F::TWP_OUT * TAPS * 8 : 0;
+#endif
+    static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL + LDS_HW;
     static constexpr int NNI = F::UNIT_OUT_S - P * C;                // non-integer-phase samples of a unit
     // LDS-DMA for the input rows (buffer_load_dwordx4 ... lds, no staging VGPRs, counted vmcnt wait): opt-in.  Measured in
     // round 2 (interleaved A/B): config 2 108.3 us with register staging vs 110.3 with LDS-DMA, config 5 613 vs 691 --
@@ -172,6 +180,14 @@ struct MarchCfg {
     static constexpr bool RNE_H = false;
 #else
     static constexpr bool RNE_H = SB == 1 && SYM;
+#endif
+    // near-integer flags per SAMPLE instead of per unit: with 16-bit samples the f32 window is 2 eps ~ 0.03 (eps scales
+    // with the sample range), a quarter of all units hold a flagged sample, and redoing every sample of such a unit in
+    // f64 was a third of config 5's time; 8-bit configurations flag one sample in 10^4 and keep the cheaper unit flag
+#ifdef LZ_MARCH_NEAR_PER_UNIT
+    static constexpr bool NEAR_PER_SAMPLE = false;
+#else
+    static constexpr bool NEAR_PER_SAMPLE = SB == 2;
 #endif
 #ifdef LZ_MARCH_NO_PK16
     static constexpr bool PK16 = false;
@@ -399,6 +415,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         const bool unit_ok = t3 < K::NU && h0 + row <= h_last && !LZ_DBG(g, 1);
         uint32_t im = 0;      // undecided integer-phase samples: bit (8*e*SB + i) <-> own input sample i*VEC + e
         bool near = false;    // some non-integer-phase sample of the unit is within eps of an integer
+        unsigned long long nearmask = 0;  // NEAR_PER_SAMPLE: which ones (bit = output sample of the unit)
         if (unit_ok) {
             const uint32_t* tin32 = (const uint32_t*)tin;
             uint32_t wd[F::NW];
@@ -503,7 +520,8 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         // sums are exactly 0, must not look "within eps of an integer"); the float -> u32 convert truncates
                         // and an unsigned min saturates: 2.5 slow-class ops per sample instead of 4
                         const float m = __builtin_fmaxf(acc, 0.5f);
-                        dmin = __builtin_fminf(dmin, __builtin_amdgcn_fractf(m));
+                        if (K::NEAR_PER_SAMPLE) nearmask |= (unsigned long long)(__builtin_amdgcn_fractf(m) < near2) << o;
+                        else dmin = __builtin_fminf(dmin, __builtin_amdgcn_fractf(m));
                         unsigned uv = (unsigned)m;                      // v_cvt_u32_f32: truncation
                         uv = uv < 65535u ? uv : 65535u;
                         ow[o / 2] |= uv << (16 * (o % 2));
@@ -511,14 +529,15 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         // below 1 / above max the store clamps: nothing to decide there
                         const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, F::MAXV + 0.5f);
                         const float fl = __builtin_floorf(xc);
-                        dmin = __builtin_fminf(dmin, xc - fl);
+                        if (K::NEAR_PER_SAMPLE) nearmask |= (unsigned long long)((xc - fl) < near2) << o;
+                        else dmin = __builtin_fminf(dmin, xc - fl);
                         if (SB == 1) ow[o / 4] = __builtin_amdgcn_cvt_pk_u8_f32(fl, o % 4, ow[o / 4]);
                         else ow[o / 2] |= (unsigned)fl << (16 * (o % 2));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            near = K::RNE_H ? dminu < __builtin_bit_cast(uint32_t, near2) : dmin < near2;
+            near = K::NEAR_PER_SAMPLE ? nearmask != 0 : (K::RNE_H ? dminu < __builtin_bit_cast(uint32_t, near2) : dmin < near2);
             // widest aligned LDS stores the unit allows
             if (F::UNIT_OUT_DW % 2 == 0) {
 #pragma unroll
@@ -567,7 +586,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         }
         if (LZ_DBG(g, 32 | 256 | 512)) {  // profiling bits: 32 no flags at all, 256 no near flags, 512 no integer flags
             if (LZ_DBG(g, 32 | 512)) im = 0;
-            if (LZ_DBG(g, 32 | 256)) near = false;
+            if (LZ_DBG(g, 32 | 256)) near = false, nearmask = 0;
         }
 
         // ---- wave-private compaction of the undecided samples, then the exact chain, densely
@@ -603,6 +622,10 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         const int ph = xl - fl * S;
 #pragma unroll
                         for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * xw[ph * kMaxTaps + k];
+                    } else if (K::LDS_HW > 0) {
+                        const double* w = (const double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL) + xl * TAPS;
+#pragma unroll
+                        for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * w[k];
                     } else {
                         const double* w = t.h_w + (size_t)xx * TAPS;
 #pragma unroll
@@ -639,7 +662,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
 #pragma unroll 1
                 for (int o = 0; o < F::UNIT_OUT_S; o++) {
                     if ((o / C) % S == 0) continue;
-                    append(near, o);
+                    append(K::NEAR_PER_SAMPLE ? (bool)((nearmask >> o) & 1) : near, o);
                     if (cnt > K::WLW - 64) flush();
                 }
                 if (cnt > 0) flush();
@@ -818,6 +841,14 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         census_t0 = __builtin_amdgcn_s_memrealtime();
         census_hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
         census_xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+    }
+    if (K::LDS_HW > 0) {  // the strip's slice of the horizontal tap table (published by the prologue's first barrier)
+        double* hwl = (double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL);
+        for (int i = tid; i < F::TWP_OUT * TAPS; i += K::NT) {
+            int xx = tx * F::TWP_OUT + i / TAPS;
+            xx = xx < g.out_w ? xx : g.out_w - 1;
+            hwl[i] = t.h_w[(size_t)xx * TAPS + i % TAPS];
+        }
     }
     // =================================================================== the march
     if (K::SPLIT) {
