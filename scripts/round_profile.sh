@@ -59,7 +59,7 @@ if f and w:
 if line:
     summ["bench_roofline"] = line.get("roofline")
     k = summ["kernels"]
-    tot = sum(v["avg_ns"] for n, v in k.items() if "k_march" in n or "k_fast" in n or "k_generic" in n or "k_prefix" in n or "k_hls" in n)
+    tot = sum(v["avg_ns"] for n, v in k.items() if "lz::" in n)
     if tot:
         summ["frac_recomputed_from_kernel_stats"] = line["roofline"]["algorithmic_bytes_per_step"] / (tot * 1e-9) / 1e9 / 8000.0
 json.dump(summ, open(out + "/summary.json", "w"), indent=1)
