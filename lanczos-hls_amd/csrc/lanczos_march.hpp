@@ -143,7 +143,7 @@ struct MarchCfg {
     // worklist entries per wave: one round of candidates.  (A list for all VEC rounds with a single dense pass
     // measured 13 % SLOWER, interleaved A/B on one device: the extra 7 KiB of LDS costs residency.)
     static constexpr int WL_ROUND = 64 * F::UNIT_IN_DW;               // most entries one round can add
-    static constexpr int WLW = WL_ROUND + 128;                        // sparse flags: all rounds share ONE dense pass
+    static constexpr int WLW = WL_ROUND + 96;                         // sparse flags: all rounds share ONE dense pass
     static constexpr int NLISTS = SPLIT ? NHW : (NU + 63) / 64;       // only waves that run the H pass keep a list
     static constexpr int LDS_TIN = 2 * TIN_BYTES;                    // double buffered
     static constexpr int LDS_HBUF = RS * H_PITCH;
@@ -156,7 +156,10 @@ struct MarchCfg {
 #else
     static constexpr int LDS_HW = (S == 3) ? F::TWP_OUT * TAPS * 8 : 0;
 #endif
-    static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL + LDS_HW;
+    // the exact chain's phase weights (TapTables::x_w: integer phase + S-1 interior phases, 256 B): a fix-up that fetches them
+    // from global memory holds its workgroup's barrier for a memory round trip
+    static constexpr int LDS_XW = kFastMaxS * kMaxTaps * 8;
+    static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL + LDS_HW + LDS_XW;
     static constexpr int NNI = F::UNIT_OUT_S - P * C;                // non-integer-phase samples of a unit
     // LDS-DMA for the input rows (buffer_load_dwordx4 ... lds, no staging VGPRs, counted vmcnt wait): opt-in.  Measured in
     // round 2 (interleaved A/B): config 2 108.3 us with register staging vs 110.3 with LDS-DMA, config 5 613 vs 691 --
@@ -509,9 +512,16 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         // unless sum lies within 2 eps below an integer, i.e. fract(acc) in [0.5, 0.5 + 2 eps): undecided.
                         // fract and the subtraction are exact; a negative difference has its sign bit set and loses the
                         // unsigned minimum.  (Sums outside [0, max] may flag spuriously: the exact chain clamps like the store.)
-                        acc = __builtin_fmaxf(acc, 0.0f);  // sum + eps' < 1/2: the store is 0 whatever the sum (keeps black regions,
-                                                           // whose sums are exactly 0, off the undecided list)
+                        // acc < 0 (sum + eps' < 1/2): the store is 0 whatever the sum.  fract(|acc|) keeps those off the undecided
+                        // list for free (the |.| is a source modifier; v_max_f32 is a slow-class op on gfx950): black regions
+                        // have acc = eps - 0.5 exactly, fract(|acc|) = 0.5 - eps, g < 0.  (Negative sums within 2 eps below
+                        // -(k + 1/2) flag spuriously: the exact chain clamps like the store.)
+#ifdef LZ_MARCH_HMAX
+                        acc = __builtin_fmaxf(acc, 0.0f);
                         const float g = __builtin_amdgcn_fractf(acc) - 0.5f;
+#else
+                        const float g = __builtin_amdgcn_fractf(__builtin_fabsf(acc)) - 0.5f;
+#endif
                         const uint32_t gu = __builtin_bit_cast(uint32_t, g);
                         dminu = gu < dminu ? gu : dminu;
                         ow[o / 4] = __builtin_amdgcn_cvt_pk_u8_f32(acc, o % 4, ow[o / 4]);
@@ -606,7 +616,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                     const int fl = xl / S;                        // floor(x) - P0
                     const T* rp = tinT + (erow * K::IN_PITCH + F::LPB) / SB + (fl - A + 1) * C + c;
                     double sum = 0;
-                    const double* xw = t.x_w;  // exact-chain weights, read from memory here (not held in SGPRs)
+                    const double* xw = (const double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL + K::LDS_HW);  // exact-chain weights
                     if (xl - fl * S == 0) {                       // integer phase: the same weights everywhere
                         if (fc.skip_last) {  // flagged samples have v0 >= 1: the ~1e-33 tap at x-i = -a is inert, L(0) is 1
 #pragma unroll
@@ -647,25 +657,46 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
             };
             // integer-phase candidates: one round per byte/halfword lane e of the own dwords (runtime loop so the
             // exact chain in flush() is not replicated per sample position); a round adds <= 64*UNIT_IN_DW entries
+            if (__any(im != 0)) {
 #pragma unroll 1
-            for (int e = 0; e <= F::VEC; e++) {  // the extra trip only drains the list (one flush() site)
-                if (e < F::VEC) {
+                for (int e = 0; e <= F::VEC; e++) {  // the extra trip only drains the list (one flush() site)
+                    if (e < F::VEC) {
 #pragma unroll
-                    for (int i = 0; i < F::UNIT_IN_DW; i++) {
-                        const int si = i * F::VEC + e, p = si / C, c = si - p * C;  // own input sample -> its integer phase
-                        append((im >> (8 * SB * e + i)) & 1, (p * S) * C + c);
+                        for (int i = 0; i < F::UNIT_IN_DW; i++) {
+                            const int si = i * F::VEC + e, p = si / C, c = si - p * C;  // own input sample -> its integer phase
+                            append((im >> (8 * SB * e + i)) & 1, (p * S) * C + c);
+                        }
                     }
+                    if (cnt > K::WLW - K::WL_ROUND || (e == F::VEC && cnt > 0)) flush();
                 }
-                if (cnt > K::WLW - K::WL_ROUND || (e == F::VEC && cnt > 0)) flush();
             }
-            if (__any(near)) {  // rare: every non-integer-phase sample of the flagged units
+            if (K::NEAR_PER_SAMPLE) {
+                if (__any(near)) {  // every flagged non-integer-phase sample
 #pragma unroll 1
-                for (int o = 0; o < F::UNIT_OUT_S; o++) {
-                    if ((o / C) % S == 0) continue;
-                    append(K::NEAR_PER_SAMPLE ? (bool)((nearmask >> o) & 1) : near, o);
-                    if (cnt > K::WLW - 64) flush();
+                    for (int o = 0; o < F::UNIT_OUT_S; o++) {
+                        if ((o / C) % S == 0) continue;
+                        append((bool)((nearmask >> o) & 1), o);
+                        if (cnt > K::WLW - 64) flush();
+                    }
+                    if (cnt > 0) flush();
                 }
-                if (cnt > 0) flush();
+            } else {
+                // rare (one unit in ~10^3), but a wave that handles one holds its workgroup's barrier: no ballot rounds -- the
+                // first NNI lanes write the flagged unit's non-integer-phase samples straight into the list
+                unsigned long long nm = __ballot(near);
+                if (nm) {
+                    const int qi = lane / C;
+                    const int o_lane = ((qi / (S - 1)) * S + qi % (S - 1) + 1) * C + lane % C;  // lane-th non-integer-phase sample
+                    do {
+                        const int src = __builtin_ctzll(nm);
+                        nm &= nm - 1;
+                        const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)ent0, src);
+                        if (lane < K::NNI) wlw[cnt + lane] = (uint16_t)(e0 + o_lane);
+                        cnt += K::NNI;
+                        if (cnt > K::WLW - K::NNI) flush();
+                    } while (nm);
+                    if (cnt > 0) flush();
+                }
             }
         }
     };
@@ -842,6 +873,8 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         census_hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
         census_xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
     }
+    if (tid < kFastMaxS * kMaxTaps)  // exact-chain phase weights (published by the prologue's first barrier)
+        ((double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL + K::LDS_HW))[tid] = t.x_w[tid];
     if (K::LDS_HW > 0) {  // the strip's slice of the horizontal tap table (published by the prologue's first barrier)
         double* hwl = (double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL);
         for (int i = tid; i < F::TWP_OUT * TAPS; i += K::NT) {
