@@ -518,6 +518,17 @@ inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTap
             if (e > eps) eps = e;
         }
     }
+    if (S == 3) {
+        // phase 2/3 mirrors phase 1/3 (L is even; the doubles differ by the rounding of x = o/3 only): the kernels keep ONE
+        // set of f32 weights for both.  Normally (float) of the two doubles is the same number; where it is not, the
+        // difference is part of the chain's error bound.
+        double dev = 0;
+        for (int k = 0; k < taps; k++) {
+            dev += std::fabs((double)fc->wf[1][taps - 1 - k] - (double)fc->wf[2][k]) * maxv;
+            fc->wf[2][k] = fc->wf[1][taps - 1 - k];
+        }
+        eps += 1.02 * dev;
+    }
     // per-index weights differ from the phase weights by the rounding of x = o/S (a few ulp of x):
     // far below the f32 slack, but count it: |dw| <= |L'| * ulp(x) <= 4 * 2^-52 * out_n
     eps += 4.0 * 2.220446049250313e-16 * (H.out_n > V.out_n ? H.out_n : V.out_n) * maxv * taps;

@@ -177,12 +177,20 @@ struct MarchCfg {
 #else
     static constexpr bool SYM = S == 2;
 #endif
-    // H pass, u8: the chain carries eps - 0.5 and the RNE byte convert is the truncating store (4-op near-integer test)
-    // (only where measured faster: with the paired chains of S = 2; at S = 3 the same change cost 30 % -- 200 vs 153 us)
+#ifdef LZ_MARCH_NO_MIRROR
+    static constexpr bool MIRROR = false;
+#else
+    static constexpr bool MIRROR = S == 3;
+#endif
+    // H pass, u8: the chain carries eps - 0.5 and the RNE byte convert is the truncating store (3-op near-integer test:
+    // fract(|acc|), subtract, unsigned min).  (S = 3: 120 -> 118 us in round 2's second half; an earlier attempt, when the
+    // kernel sat on a register step, had cost 30 %.)
 #ifdef LZ_MARCH_OLD_NEAR
     static constexpr bool RNE_H = false;
-#else
+#elif defined(LZ_MARCH_RNE_SYM_ONLY)
     static constexpr bool RNE_H = SB == 1 && SYM;
+#else
+    static constexpr bool RNE_H = SB == 1;
 #endif
     // near-integer flags per SAMPLE instead of per unit: with 16-bit samples the f32 window is 2 eps ~ 0.03 (eps scales
     // with the sample range), a quarter of all units hold a flagged sample, and redoing every sample of such a unit in
@@ -352,7 +360,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     u32x4 pre[K::LOAD_IT];
     // (RIDE: per-lane indices are rebuilt every tick from an opaque copy of the thread id -- a handful of instructions --
     // instead of being held in registers across the other phases: the kernel sits on its 72-VGPR budget.)
-    auto issue_loads = [&](int tick) {
+    auto issue_loads_to = [&](int tick, u32x4 (&dst)[K::LOAD_IT]) {
         int t1 = tid;
         if (RIDE || STAMP || K::SPLIT || K::OPAQUE_IDX) asm volatile("" : "+v"(t1));
 #pragma unroll
@@ -372,9 +380,15 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                     irsrc, (__attribute__((address_space(3))) void*)(smem + (tick & 1) * K::TIN_BYTES + (wave * 64 + it * K::NLT) * 16),
                     16, off, 0, 0, 0);
             } else {
-                pre[it] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);
+                dst[it] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);
             }
         }
+    };
+    auto issue_loads = [&](int tick) { issue_loads_to(tick, pre); };
+    auto commit_from = [&](int buf, const u32x4 (&src)[K::LOAD_IT]) {
+#pragma unroll
+        for (int it = 0; it < K::LOAD_IT; it++)
+            *(u32x4*)(smem + buf * K::TIN_BYTES + (tid + it * K::NLT) * 16) = src[it];
     };
     auto commit_loads = [&](int buf) {
         if (K::LDSDMA) {  // the issuing wave's vmcnt covers its LDS-DMA; the tick's barrier publishes it to the other waves
@@ -389,14 +403,18 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     // ---- phase weights, pinned in VGPRs for the whole march.  Measured on gfx950 (scripts/probes/probe_valu3.hip): a VALU
     // instruction with an SGPR source issues at ~1.9 ns per wave, the same instruction with VGPR / inline-constant
     // sources at ~1.1 ns -- so the (S-1)*2a weights cost registers, not the constant bus.
-    float wv[S][TAPS];
+    // S = 3: phase 2/3 is the mirror image of phase 1/3 (fast_prepare makes wf[2][k] == wf[1][2a-1-k] bit for bit and
+    // prices the difference into eps): one set of registers serves both
+    constexpr int NPHW = K::MIRROR ? 2 : S;
+    float wv_[NPHW][TAPS];
 #pragma unroll
-    for (int ph = 1; ph < S; ph++)
+    for (int ph = 1; ph < NPHW; ph++)
 #pragma unroll
         for (int k = 0; k < TAPS; k++) {
-            wv[ph][k] = fc.wf[ph][k];
-            asm volatile("" : "+v"(wv[ph][k]));
+            wv_[ph][k] = fc.wf[ph][k];
+            asm volatile("" : "+v"(wv_[ph][k]));
         }
+    auto wv = [&](int ph, int k) -> float { return (K::MIRROR && ph == 2) ? wv_[1][TAPS - 1 - k] : wv_[ph][k]; };
     constexpr uint32_t HALF = SB == 1 ? 0x80u : 0x8000u;
     const uint32_t addc1 = (uint32_t)fc.vlim < HALF - 1 ? HALF - 1 - (uint32_t)fc.vlim : 0;
     // the chain bias and the SWAR masks live in VGPRs for the same reason (a literal is a constant-bus read too)
@@ -497,12 +515,12 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                     if (K::SYM) {
 #pragma unroll
                         for (int k = 0; k < A; k++)  // outside in; the pair sums are exact (<= 2 * max sample)
-                            acc = __builtin_fmaf(wv[ph][k], fch[p + k] + fch[p + TAPS - 1 - k], acc);
+                            acc = __builtin_fmaf(wv(ph, k), fch[p + k] + fch[p + TAPS - 1 - k], acc);
                     } else {
 #pragma unroll
                         for (int j = 0; j < TAPS; j++) {
                             const int k = f32_tap_order(j, TAPS);  // outside in: the bound of fc.bias assumes this order
-                            acc = __builtin_fmaf(wv[ph][k], fch[p + k], acc);
+                            acc = __builtin_fmaf(wv(ph, k), fch[p + k], acc);
                         }
                     }
                     const int o = q * C + c;
@@ -794,12 +812,12 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                             if (K::SYM) {
 #pragma unroll
                                 for (int k = 0; k < A; k++)
-                                    acc = __builtin_fmaf(wv[ph][k], win[(i + k) % TAPS][e] + win[(i + TAPS - 1 - k) % TAPS][e], acc);
+                                    acc = __builtin_fmaf(wv(ph, k), win[(i + k) % TAPS][e] + win[(i + TAPS - 1 - k) % TAPS][e], acc);
                             } else {
 #pragma unroll
                                 for (int j = 0; j < TAPS; j++) {
                                     const int k = f32_tap_order(j, TAPS);
-                                    acc = __builtin_fmaf(wv[ph][k], win[(i + k) % TAPS][e], acc);
+                                    acc = __builtin_fmaf(wv(ph, k), win[(i + k) % TAPS][e], acc);
                                 }
                             }
                             accs[e] = acc;
@@ -915,10 +933,18 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         }
         return;
     }
-    issue_loads(0);
-    commit_loads(0);
-    issue_loads(1);
-    commit_loads(1);
+    if (K::LDSDMA) {
+        issue_loads(0);
+        commit_loads(0);
+        issue_loads(1);
+        commit_loads(1);
+    } else {  // both ticks' loads in flight at once (one memory round trip instead of two per chunk)
+        u32x4 pre0[K::LOAD_IT];
+        issue_loads_to(0, pre0);
+        issue_loads(1);
+        commit_from(0, pre0);
+        commit_loads(1);
+    }
     __syncthreads();
     hpass(0);
     __syncthreads();
@@ -986,16 +1012,19 @@ inline bool march_supports(const FrameGeom& g) {
 // Chunk height: ONE resident round of workgroups.  With more workgroups than the chip holds at once the second
 // round runs part-empty and the launch takes two wave lifetimes; so the (strip, frame) pairs are cut into
 // floor(slots / pairs) chunks each (at least one, a whole number of ticks, at least two ticks).
-inline int march_chunk_rows(int m_rows, int strips, int frames, int ms, int slots) {
+// A chunk of R rows marches over R + 2a - 1 H rows (its window reaches a - 1 rows above and a rows below), i.e.
+// ceil((R + 2a - 1) / MS) ticks: R is rounded up to "a whole number of ticks minus the window" so that no tick is spent on
+// window rows alone (16 x 1080p: 271-row chunks in 23 ticks where 276-row chunks took 24).
+inline int march_chunk_rows(int m_rows, int strips, int frames, int ms, int slots, int taps) {
     static const int target_env = getenv("LANCZOS_MARCH_WGS") ? atoi(getenv("LANCZOS_MARCH_WGS")) : 0;
     const int target = target_env > 0 ? target_env : slots;
     const int pairs = strips * frames;
     int chunks = target / pairs;
     if (chunks < 1) chunks = 1;
     int rows = (m_rows + chunks - 1) / chunks;
-    rows = (rows + ms - 1) / ms * ms;
-    if (rows < 2 * ms) rows = 2 * ms;
-    return rows;
+    int ticks = (rows + taps - 1 + ms - 1) / ms;
+    if (ticks < 3) ticks = 3;
+    return ticks * ms - (taps - 1);
 }
 
 template <typename T, int C, int S, int A>
@@ -1040,7 +1069,7 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
             fprintf(stderr, "lanczos: k_march<%d B,%d ch,x%d,a=%d> %d threads, %d B LDS: %d workgroups/CU x %d CUs\n",
                     (int)sizeof(T), C, S, A, K::NT, K::LDS_BYTES, nb, cus);
     }
-    const int chunk_rows = march_chunk_rows(m_rows, strips, g.frames, K::MS, slots[exact_][dev_]);
+    const int chunk_rows = march_chunk_rows(m_rows, strips, g.frames, K::MS, slots[exact_][dev_], K::TAPS);
     const int chunks = (m_rows + chunk_rows - 1) / chunk_rows;
     g.wg_per_frame = strips * chunks;
     g.n_main = g.wg_per_frame * g.frames;
