@@ -60,6 +60,16 @@
 #define LZ_DBG(g, bits) false
 #endif
 
+// cache policy of the input-row loads (aux bits of the buffer load: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef LZ_MARCH_LOAD_AUX
+#define LZ_MARCH_LOAD_AUX 0
+#endif
+#ifdef LZ_RIDE_NO_REBUILD
+#define LZ_RIDE_REBUILD(ride) false
+#else
+#define LZ_RIDE_REBUILD(ride) (ride)
+#endif
+
 namespace lz {
 
 // SPLIT (role-specialised waves): the first NHW waves of a workgroup run ONLY the H pass (+ fix-ups), the others ONLY the V
@@ -176,6 +186,16 @@ struct MarchCfg {
     static constexpr bool SYM = false;
 #else
     static constexpr bool SYM = S == 2;
+#endif
+    // the input rows of tick t + 3 are requested a whole tick (a V pass, the barrier, an H pass) before they are committed to
+    // LDS instead of one H pass before: +4 staging registers through the V pass.  Pays where LDS, not registers, limits
+    // residency (16-bit samples: config 5 634 -> 617 us); on config 2 the four registers cost the fourth workgroup (224 -> 272 us)
+#if defined(LZ_MARCH_EARLY_ISSUE)
+    static constexpr bool EARLY = true;
+#elif defined(LZ_MARCH_NO_EARLY_ISSUE)
+    static constexpr bool EARLY = false;
+#else
+    static constexpr bool EARLY = SB == 2;
 #endif
 #ifdef LZ_MARCH_NO_MIRROR
     static constexpr bool MIRROR = false;
@@ -362,7 +382,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     // instead of being held in registers across the other phases: the kernel sits on its 72-VGPR budget.)
     auto issue_loads_to = [&](int tick, u32x4 (&dst)[K::LOAD_IT]) {
         int t1 = tid;
-        if (RIDE || STAMP || K::SPLIT || K::OPAQUE_IDX) asm volatile("" : "+v"(t1));
+        if (LZ_RIDE_REBUILD(RIDE) || STAMP || K::SPLIT || K::OPAQUE_IDX) asm volatile("" : "+v"(t1));
 #pragma unroll
         for (int it = 0; it < K::LOAD_IT; it++) {
             const int idx = t1 + it * K::NLT;
@@ -380,7 +400,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                     irsrc, (__attribute__((address_space(3))) void*)(smem + (tick & 1) * K::TIN_BYTES + (wave * 64 + it * K::NLT) * 16),
                     16, off, 0, 0, 0);
             } else {
-                dst[it] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);
+                dst[it] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, LZ_MARCH_LOAD_AUX);
             }
         }
     };
@@ -431,7 +451,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         const uint8_t* tin = smem + (tick & 1) * K::TIN_BYTES;
         const int h0 = hb + tick * K::MS;           // first H row of the tick
         int t3 = tid;
-        if (RIDE || STAMP || K::SPLIT || K::OPAQUE_IDX) asm volatile("" : "+v"(t3));
+        if (LZ_RIDE_REBUILD(RIDE) || STAMP || K::SPLIT || K::OPAQUE_IDX) asm volatile("" : "+v"(t3));
         const int row = t3 / K::UPR, u = t3 % K::UPR;
         const bool unit_ok = t3 < K::NU && h0 + row <= h_last && !LZ_DBG(g, 1);
         uint32_t im = 0;      // undecided integer-phase samples: bit (8*e*SB + i) <-> own input sample i*VEC + e
@@ -741,7 +761,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     // other vector-memory instruction: the march loop then waits for its input prefetch with a counted vmcnt
     auto vpass = [&](int tick) -> bool {
         int t2 = K::SPLIT ? tid - K::NHW * 64 : tid;
-        if (RIDE || STAMP || K::OPAQUE_IDX) asm volatile("" : "+v"(t2));
+        if (LZ_RIDE_REBUILD(RIDE) || STAMP || K::OPAQUE_IDX) asm volatile("" : "+v"(t2));
         const int grp = K::NGRP == 1 ? (t2 < K::NVT ? 0 : 1) : grp_w;
         const int col = t2 - grp * K::NVT_PAD;
         const unsigned col_b = (unsigned)(tx * F::TWB_OUT + col * 4);
@@ -803,6 +823,8 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                                 undecided |= fl;
                             }
                         }
+                    } else if (LZ_DBG(g, 1024)) {  // profiling bit 1024: computed rows are copies too (loads + stores, no V arithmetic)
+                        packed = raw[(i + A - 1) % TAPS];
                     } else {
                         packed = 0;
                         float accs[F::VEC];
@@ -944,6 +966,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         issue_loads(1);
         commit_from(0, pre0);
         commit_loads(1);
+        if (K::EARLY) issue_loads(2);
     }
     __syncthreads();
     hpass(0);
@@ -961,7 +984,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     };
     for (int tick = 0; tick < ticks; tick++) {
         const unsigned long long t0 = stamp();
-        if (!K::LDSDMA) issue_loads(tick + 2);  // lands in the buffer HPASS(tick) has finished with
+        if (!K::LDSDMA && !K::EARLY) issue_loads(tick + 2);  // lands in the buffer HPASS(tick) has finished with
         const unsigned long long t1 = stamp();
         // Wave priority by phase (measured, interleaved on one device: H=3/V=2/else=0 is 11-13 % faster than all
         // equal): the H pass feeds the ring every other wave's next V pass waits for, so it goes first.
@@ -975,6 +998,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         // with vmcnt(0) in front of the V pass stood behind the previous tick's stores: 'no loads' ablation -15 us).
         if (K::LDSDMA) issue_loads(tick + 2);
         else commit_loads(tick & 1);
+        if (!K::LDSDMA && K::EARLY) issue_loads(tick + 3);  // committed after the NEXT tick's H pass (see MarchCfg::EARLY)
         const unsigned long long t3 = stamp();
         __builtin_amdgcn_s_setprio(2);
         const bool full = vpass(tick);
@@ -1017,12 +1041,25 @@ inline bool march_supports(const FrameGeom& g) {
 // window rows alone (16 x 1080p: 271-row chunks in 23 ticks where 276-row chunks took 24).
 inline int march_chunk_rows(int m_rows, int strips, int frames, int ms, int slots, int taps) {
     static const int target_env = getenv("LANCZOS_MARCH_WGS") ? atoi(getenv("LANCZOS_MARCH_WGS")) : 0;
-    const int target = target_env > 0 ? target_env : slots;
     const int pairs = strips * frames;
-    int chunks = target / pairs;
-    if (chunks < 1) chunks = 1;
-    int rows = (m_rows + chunks - 1) / chunks;
-    int ticks = (rows + taps - 1 + ms - 1) / ms;
+    auto ticks_of = [&](int chunks) { return ((m_rows + chunks - 1) / chunks + taps - 1 + ms - 1) / ms; };
+    int chunks = 1;
+    if (target_env > 0) {
+        chunks = target_env / pairs;
+        if (chunks < 1) chunks = 1;
+    } else {
+        // rounds of resident workgroups x (ticks of a chunk + its prologue, about two ticks): one full round where the batch
+        // allows it; when floor(slots / pairs) chunks would leave the machine part-empty (pairs between slots / 2 and slots:
+        // 32 frames of 720p, 320 pairs on 512 slots ran on 62 % of the chip), more and shorter chunks in two or three rounds
+        long best = -1;
+        for (int c = 1; c <= 512; c++) {
+            if (c > 1 && ticks_of(c) < 3) break;
+            const long rounds = ((long)pairs * c + slots - 1) / slots;
+            const long cost = rounds * (ticks_of(c) + 2);
+            if (best < 0 || cost < best) best = cost, chunks = c;
+        }
+    }
+    int ticks = ticks_of(chunks);
     if (ticks < 3) ticks = 3;
     return ticks * ms - (taps - 1);
 }
@@ -1080,7 +1117,8 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || cus < 1) cus = 256;
-        if (g.prefix_blocks_per_frame * g.frames > cus) {
+        static const bool ride_always = getenv("LANCZOS_RIDE_ALWAYS") && atoi(getenv("LANCZOS_RIDE_ALWAYS")) != 0;  // experiments
+        if (g.prefix_blocks_per_frame * g.frames > cus && !ride_always) {
             g.prefix_K = g.prefix_M = g.prefix_M2 = g.prefix_blocks_per_frame = 0;
             *prefix_fused = false;
         }

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--frames", type=int, default=0)
     ap.add_argument("--mode", default="lsb1")
     ap.add_argument("--check", action="store_true", help="compare every library's output with the first one's")
+    ap.add_argument("--rotate", type=int, default=1, help="cycle through this many distinct input batches (and output buffers) step by step")
+    ap.add_argument("--rotate-what", default="both", choices=["both", "in", "out"], help="which side --rotate cycles")
     args = ap.parse_args()
 
     import torch
@@ -63,17 +65,24 @@ def main():
 
     all_keys = {k for _s, _l, _h, env in handles for k in env}
 
+    ys = [y] + [torch.empty_like(y) for _ in range(args.rotate - 1)]
+    rot = [0]
+
     def run(lib, h, env, x, n):
         for k in all_keys:      # a library sees only its own overrides (some are read once, at the first call)
             os.environ.pop(k, None)
         for k, v in env.items():
             os.environ[k] = v
         for _ in range(n):
-            rc = lib.lanczos_resample_device(h, ctypes.byref(d), x.data_ptr(), y.data_ptr(), frames, 0, 0, stream)
+            i = rot[0] % args.rotate
+            rot[0] += 1
+            ii = i if args.rotate_what in ("both", "in") else 0
+            io = i if args.rotate_what in ("both", "out") else 0
+            rc = lib.lanczos_resample_device(h, ctypes.byref(d), x[ii].data_ptr(), ys[io].data_ptr(), frames, 0, 0, stream)
             assert rc == 0, rc
 
     for pat in args.patterns.split(","):
-        x = bench.make_frames(torch, pat, frames, ih, iw, c, bps, dev, 1234)
+        x = [bench.make_frames(torch, pat, frames, ih, iw, c, bps, dev, 1234 + i) for i in range(args.rotate)]
         res = {spec: [] for spec, *_ in handles}
         ref_out = None
         for spec, lib, h, env in handles:   # warm-up (+ optional output comparison)
