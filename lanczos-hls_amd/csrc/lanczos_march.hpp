@@ -235,7 +235,9 @@ struct MarchCfg {
 #endif
     // per-lane indices rebuilt every tick from an opaque copy of the thread id instead of living in registers across the
     // phases (what the RIDE variant does): configurations that sit just above an occupancy step
-#ifdef LZ_MARCH_C3_OPAQUE
+#if defined(LZ_MARCH_OPAQUE_ALL)
+    static constexpr bool OPAQUE_IDX = true;
+#elif defined(LZ_MARCH_C3_OPAQUE)
     static constexpr bool OPAQUE_IDX = SB == 1 && C == 3 && S == 3;
 #else
     static constexpr bool OPAQUE_IDX = false;
