@@ -68,6 +68,7 @@ struct lanczos_ctx {
     int launches = 0;
     double main_ms = 0, prefix_ms = 0;
     void* stamp_buf = nullptr;
+    lz::WgTabCache wg_tabs;  // k_march's workgroup tables (device copies), one per launch shape
     hipStream_t copy_in = nullptr, copy_out = nullptr;  // lanczos_resample_host pipeline
     // the in-place prefix rows of integer scales run on a side stream BESIDE the marching kernel (k_prefix_reg)
     hipStream_t side = nullptr;
@@ -620,7 +621,7 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
                 gm.prefix_K = p->prefix.K;
                 gm.prefix_M = p->prefix.M;
                 gm.prefix_M2 = p->prefix.M2;
-                e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &prefix_fused, /*query_only=*/true);
+                e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &prefix_fused, &ctx->wg_tabs, /*query_only=*/true);
                 if (e == hipSuccess && !prefix_fused) {
                     // Large batch: the prefix rows neither ride nor wait -- the register-only kernel goes out FIRST, on the
                     // side stream, and shares the CUs with the marching kernel's first microseconds (it needs no LDS, the
@@ -639,7 +640,7 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
             } else {
                 e = hipSuccess;
             }
-            if (e == hipSuccess) e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &prefix_fused);
+            if (e == hipSuccess) e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &prefix_fused, &ctx->wg_tabs);
         }
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;

@@ -16,6 +16,11 @@
 
 namespace lz {
 
+// one marching workgroup's share: strip `tx` of frame `frame`, input-row-indexed output rows m in [m_b, m_e)
+struct WgEntry {
+    int frame, tx, m_b, m_e;
+};
+
 struct FrameGeom {
     // all pitches/strides in BYTES; dims in pixels; sample = one channel of one pixel
     const uint8_t* in;   // first input row held by the caller (= full-frame row in_row0)
@@ -34,6 +39,7 @@ struct FrameGeom {
     // k_prefix); prefix_K == 0: a separate k_prefix launch does that
     int n_main, wg_per_frame, prefix_blocks_per_frame, prefix_K, prefix_M, prefix_M2;
     int debug_skip;       // ablation bits for profiling builds (0 in production): 1 H-pass, 2 fix-up, 4 V-pass, 8 stores, 16 loads
+    const WgEntry* wg_tab; // k_march only: [n_main] share of every marching workgroup, indexed by the hardware block id
 };
 
 struct TapTables {

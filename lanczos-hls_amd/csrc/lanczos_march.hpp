@@ -35,6 +35,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <algorithm>
+#include <cstring>
+#include <utility>
+#include <vector>
 
 #include "lanczos_fast.hpp"
 
@@ -258,8 +262,7 @@ struct MarchCfg {
 // no separate k_prefix launch).  That variant rebuilds its per-lane indices every tick to stay inside the register
 // budget; the batch variant (RIDE = false) holds them in registers, which is 2-3 % faster when the chip is full.
 template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
-__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::MIN_WAVES)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc,
-                                                                      int chunk_rows) {
+__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::MIN_WAVES)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
     constexpr int TAPS = K::TAPS, SB = K::SB;
@@ -339,28 +342,21 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         return;
     }
 
-    const int strips = (g.out_w + F::TWP_OUT - 1) / F::TWP_OUT;
-    // XCD-aware placement.  Workgroups go round-robin to the 8 XCDs by linear id (verified: profiles/round1c census),
-    // and every XCD has its own L2.  A strip's 16-byte halo chunks pull in its neighbours' 128-byte lines, so with the
-    // natural order (neighbouring strips on different XCDs) every input line is fetched 5/3 times (measured: 164 MB read
-    // for 99.5 MB of input).  Remapped, the ids an XCD receives are consecutive (whole frames in the benchmark's launch):
-    // neighbours share an L2.
-    const int nwg = g.n_main, wid = blockIdx.x;
-    // (Measured, config 2: read traffic 160 MB -> 98.9 MB per launch, 112.7 -> 108.5 us.  Sharing an XCD only among the
-    // strips of one band and spreading the bands round-robin was slower: 119 us.)  Profiling bit 4096 = natural order.
-    // XCD x receives the ids x, x+8, ...: (nwg - x + 7) / 8 of them; they are renumbered consecutively behind XCD x-1's.
-    const int xcd = wid & 7, xq = nwg >> 3, xr = nwg & 7;
-    const int lid = !LZ_DBG(g, 4096) ? xcd * xq + (xcd < xr ? xcd : xr) + (wid >> 3) : wid;
-    const int frame = lid / g.wg_per_frame;
-    const int tx = (lid - frame * g.wg_per_frame) % strips;
-    const int chunk = (lid - frame * g.wg_per_frame) / strips;
+    // Which strip, which frame, which rows: one table entry per hardware block id, built on the host (march_build_table):
+    //   * XCD-aware placement.  Workgroups go round-robin to the 8 XCDs by block id (verified: profiles/round1c census) and
+    //     every XCD has its own L2.  A strip's 16-byte halo chunks pull in its neighbours' 128-byte lines, so with the natural
+    //     order (neighbouring strips on different XCDs) every input line is fetched 5/3 times (measured: 164 MB read for
+    //     99.5 MB of input).  The ids one XCD receives cover whole frames: neighbours share an L2 (160 -> 98.9 MB per launch).
+    //   * rank-aware shares.  Inside an XCD the dispatcher fills the CUs breadth first (block id / 8 / 32 = rank of the
+    //     workgroup on its CU) and the SIMD arbiter serves older waves first: with equal shares the 1st..4th workgroup of a CU
+    //     took 179 / 189 / 197 / 207 us, the three of a CU that got only three 152 / 164 / 179 us, and the launch ended in a
+    //     70 us tail of half-empty CUs (profiles/round2e_census_32frames.txt).  The table gives faster slots more rows.
+    const WgEntry we = g.wg_tab[blockIdx.x];  // uniform: scalar loads
+    const int frame = we.frame, tx = we.tx, m_b = we.m_b, m_e = we.m_e;
 
     // rows: m = floor(y/S) is the input row an output row hangs on.  This workgroup owns m in [m_b, m_e).
     const int y_lo = g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows;  // first output row stored at all
     const int y_hi = g.out_row0 + g.out_rows;                               // one past the last
-    const int m_b = y_lo / S + chunk * chunk_rows;
-    int m_e = m_b + chunk_rows;
-    if (m_e > (y_hi - 1) / S + 1) m_e = (y_hi - 1) / S + 1;
     if (m_b >= m_e) return;
     const int hb = m_b - (A - 1);           // first H row (= input row) this chunk needs
     const int h_last = m_e - 1 + A;         // last one
@@ -1066,9 +1062,158 @@ inline int march_chunk_rows(int m_rows, int strips, int frames, int ms, int slot
     return ticks * ms - (taps - 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The workgroup table (see the kernel: "Which strip, which frame, which rows").
+//
+// Hardware facts it encodes (MI355X, profiles/round2e_census_32frames.txt; wrong facts only cost speed, never results):
+//   block id b runs on XCD b % 8; inside an XCD the j-th block (j = b / 8) is the (j / CU_X)-th workgroup of CU j % CU_X
+//   (CU_X = CUs per XCD = 32): the dispatcher fills the CUs breadth first.  A CU's earlier workgroups run faster (older
+//   waves win the SIMD arbitration), and a CU that received one workgroup fewer runs each of them faster still.
+// speed[] below = rows per unit time of such a slot relative to the mean, from measured lifetimes with equal shares;
+// LANCZOS_RANK_WEIGHTS="w0:w1:w2:w3/v0:v1:v2" overrides (full CUs; CUs one short), LANCZOS_RANK_WEIGHTS=0 = equal shares.
+struct MarchSlotSpeed {
+    double full[8], shorty[8];
+};
+inline MarchSlotSpeed march_slot_speed(int nb, int nwaves) {
+    MarchSlotSpeed w;
+    for (int i = 0; i < 8; i++) w.full[i] = w.shorty[i] = 1.0;
+    if (nb == 4) {
+        const double f[4] = {1.060, 1.008, 0.964, 0.918}, s3[3] = {1.246, 1.156, 1.064};
+        for (int i = 0; i < 4; i++) w.full[i] = f[i];
+        for (int i = 0; i < 3; i++) w.shorty[i] = s3[i];
+    } else if (nb == 2 && nwaves % 4 != 0) {
+        // 6-wave workgroups, two per CU (config 3: 123 -> 117 us at 16 frames); 8-wave workgroups put two waves on every SIMD
+        // and showed no rank effect (config 5, 4 frames: 315 us with equal shares, 320 with these)
+        w.full[0] = 1.04, w.full[1] = 0.96, w.shorty[0] = 1.20;
+    } else if (nb == 3) {
+        w.full[0] = 1.05, w.full[1] = 1.0, w.full[2] = 0.95, w.shorty[0] = 1.18, w.shorty[1] = 1.10;
+    }
+    if (const char* e = getenv("LANCZOS_RANK_WEIGHTS")) {
+        if (atof(e) == 0.0 && e[0] == '0') {
+            for (int i = 0; i < 8; i++) w.full[i] = w.shorty[i] = 1.0;
+        } else {
+            const char* p = e;
+            double* dst = w.full;
+            int i = 0;
+            while (*p) {
+                char* end = nullptr;
+                const double v = strtod(p, &end);
+                if (end == p) break;
+                if (i < 8) dst[i++] = v;
+                p = end;
+                if (*p == ',' || *p == ':') p++;
+                else if (*p == ';' || *p == '/') p++, dst = w.shorty, i = 0;
+            }
+        }
+    }
+    return w;
+}
+
+// rows of a chunk that end on a tick boundary: ticks * MS - (2a - 1)
+inline int march_align_rows(int rows, int ms, int taps) {
+    int t = (rows + taps - 1 + ms / 2) / ms;  // nearest
+    if (t < 2) t = 2;
+    return t * ms - (taps - 1);
+}
+
+// Fills `tab` (indexed by hardware block id) for `strips` x `frames` pairs whose rows [m_lo, m_hi) are cut into chunks.
+// Returns the number of marching workgroups.
+inline int march_build_table(std::vector<WgEntry>& tab, int strips, int frames, int m_lo, int m_hi, int ms, int taps, int nb,
+                             int cus, int nwaves, bool* balanced_out) {
+    const int m_rows = m_hi - m_lo, slots = nb * cus, pairs = strips * frames;
+    const int rows_u = march_chunk_rows(m_rows, strips, frames, ms, slots, taps);
+    const int chunks = (m_rows + rows_u - 1) / rows_u;
+    const int n = pairs * chunks;
+    tab.assign(n, WgEntry{0, 0, 0, 0});
+    const int nx = 8, cu_x = cus / nx > 0 ? cus / nx : 1;
+    // pairs (frame-major: neighbouring strips consecutive) are dealt to the XCDs in consecutive runs; XCD x owns the
+    // hardware ids x, x + 8, ...: (n - x + 7) / 8 of them
+    const MarchSlotSpeed sp = march_slot_speed(nb, nwaves);
+    bool balanced = n <= slots && chunks >= 2 && cus % nx == 0;
+    for (int x = 0; x < nx && balanced; x++)
+        if (((n - x + nx - 1) / nx) % chunks != 0) balanced = false;
+    if (balanced) {
+        bool any = false;
+        for (int i = 0; i < 8; i++) any = any || sp.full[i] != 1.0 || sp.shorty[i] != 1.0;
+        balanced = any;
+    }
+    *balanced_out = balanced;
+    int pair0 = 0, lid0 = 0;
+    for (int x = 0; x < nx; x++) {
+        const int n_x = (n - x + nx - 1) / nx;
+        if (!balanced) {
+            // equal shares: the ids of XCD x are renumbered consecutively behind XCD x-1's; chunk-major inside a frame
+            for (int j = 0; j < n_x; j++) {
+                const int lid = lid0 + j, frame = lid / (strips * chunks), q = lid - frame * strips * chunks;
+                const int tx = q % strips, c = q / strips;
+                const int b = m_lo + c * rows_u, e = b + rows_u < m_hi ? b + rows_u : m_hi;
+                tab[(size_t)j * nx + x] = WgEntry{frame, tx, b, e};
+            }
+            lid0 += n_x;
+            continue;
+        }
+        // slot speeds of this XCD's workgroups
+        std::vector<std::pair<double, int>> sj(n_x);
+        for (int j = 0; j < n_x; j++) {
+            const int rank = j / cu_x, c = j % cu_x;
+            const int on_cu = (n_x - c + cu_x - 1) / cu_x;
+            double v = 1.0;
+            if (rank < 8) v = on_cu >= nb ? sp.full[rank] : (on_cu == nb - 1 ? sp.shorty[rank] : 1.0);
+            sj[j] = {v, j};
+        }
+        std::sort(sj.begin(), sj.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
+            return a.first != b.first ? a.first > b.first : a.second < b.second;
+        });
+        // groups of `chunks` slots with near-equal speed sums: deal the sorted slots out in snake order
+        const int groups = n_x / chunks;
+        std::vector<std::vector<std::pair<double, int>>> grp(groups);
+        for (int i = 0; i < n_x; i++) {
+            const int round = i / groups, pos = i % groups;
+            grp[(round & 1) ? groups - 1 - pos : pos].push_back(sj[i]);
+        }
+        for (int gi = 0; gi < groups; gi++) {
+            const int pair = pair0 + gi, frame = pair / strips, tx = pair % strips;
+            auto& mem = grp[gi];
+            std::sort(mem.begin(), mem.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.second < b.second; });
+            double tot = 0;
+            for (auto& m : mem) tot += m.first;
+            int b = m_lo;
+            double acc = 0;
+            for (size_t k = 0; k < mem.size(); k++) {
+                acc += mem[k].first;
+                int e;
+                if (k + 1 == mem.size()) e = m_hi;
+                else {
+                    const int want = (int)(m_lo + m_rows * acc / tot + 0.5) - b;
+                    e = b + march_align_rows(want, ms, taps);
+                    if (e > m_hi) e = m_hi;
+                }
+                tab[(size_t)mem[k].second * nx + x] = WgEntry{frame, tx, b, e};
+                b = e;
+            }
+        }
+        pair0 += groups;
+    }
+    return n;
+}
+
+// device copies of the tables a context has used (callers serialise per context; a handful of entries)
+struct WgTabCache {
+    struct Item {
+        long long key[8];
+        WgEntry* dev;
+        int n;
+        bool balanced;
+    };
+    std::vector<Item> items;
+    ~WgTabCache() {
+        for (auto& it : items) (void)hipFree(it.dev);
+    }
+};
+
 template <typename T, int C, int S, int A>
 inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, const TapTables& t,
-                                 const FastConsts& fc, hipStream_t stream, bool* prefix_fused, bool query_only) {
+                                 const FastConsts& fc, hipStream_t stream, bool* prefix_fused, bool query_only, WgTabCache* cache) {
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
     FrameGeom g = g_in;
@@ -1085,7 +1230,6 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     const int y_lo = g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows;
     const int y_hi = g.out_row0 + g.out_rows;
     if (y_lo >= y_hi) return hipSuccess;
-    const int m_rows = (y_hi - 1) / S - y_lo / S + 1;
     std::lock_guard<std::mutex> cache_lock(launch_cache_mutex());  // slots[], attr_done[], ride_attr_done[] below
     static int slots[2][64] = {};
     const bool exact_ = d.mode == LANCZOS_MODE_EXACT;
@@ -1108,10 +1252,43 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
             fprintf(stderr, "lanczos: k_march<%d B,%d ch,x%d,a=%d> %d threads, %d B LDS: %d workgroups/CU x %d CUs\n",
                     (int)sizeof(T), C, S, A, K::NT, K::LDS_BYTES, nb, cus);
     }
-    const int chunk_rows = march_chunk_rows(m_rows, strips, g.frames, K::MS, slots[exact_][dev_], K::TAPS);
-    const int chunks = (m_rows + chunk_rows - 1) / chunk_rows;
-    g.wg_per_frame = strips * chunks;
-    g.n_main = g.wg_per_frame * g.frames;
+    static int cus_of[64] = {};
+    if (cus_of[dev_] == 0 && (hipDeviceGetAttribute(&cus_of[dev_], hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || cus_of[dev_] < 1))
+        cus_of[dev_] = 256;
+    const int nb_ = slots[exact_][dev_] / cus_of[dev_] > 0 ? slots[exact_][dev_] / cus_of[dev_] : 1;
+    // the workgroup table of this launch shape (built once per context and shape)
+    const int m_lo = y_lo / S, m_hi = (y_hi - 1) / S + 1;
+    const long long key[8] = {(long long)sizeof(T) | ((long long)C << 8) | ((long long)S << 16) | ((long long)A << 24) | ((long long)exact_ << 32),
+                              strips, g.frames, m_lo, m_hi, nb_, cus_of[dev_], dev_};
+    const WgTabCache::Item* item = nullptr;
+    for (const auto& it : cache->items)
+        if (memcmp(it.key, key, sizeof(key)) == 0) item = &it;
+    if (!item) {
+        std::vector<WgEntry> tab;
+        bool balanced = false;
+        const int n = march_build_table(tab, strips, g.frames, m_lo, m_hi, K::MS, K::TAPS, nb_, cus_of[dev_], K::NWAVES, &balanced);
+        WgTabCache::Item it;
+        memcpy(it.key, key, sizeof(key));
+        it.n = n;
+        it.balanced = balanced;
+        it.dev = nullptr;
+        hipError_t e = hipMalloc(&it.dev, sizeof(WgEntry) * (size_t)n);
+        if (e == hipSuccess) e = hipMemcpy(it.dev, tab.data(), sizeof(WgEntry) * (size_t)n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+        if (cache->items.size() >= 64) {  // bounded: drop the oldest shape (nothing in flight uses it once its stream has drained)
+            (void)hipDeviceSynchronize();
+            (void)hipFree(cache->items.front().dev);
+            cache->items.erase(cache->items.begin());
+        }
+        cache->items.push_back(it);
+        item = &cache->items.back();
+        if (getenv("LANCZOS_VERBOSE"))
+            fprintf(stderr, "lanczos: k_march table: %d workgroups for %d strips x %d frames, rows [%d, %d): %s shares\n", n, strips,
+                    g.frames, m_lo, m_hi, balanced ? "rank-aware" : "equal");
+    }
+    g.wg_tab = item->dev;
+    g.wg_per_frame = 0;
+    g.n_main = item->n;
     g.prefix_blocks_per_frame = g.prefix_K > 0 ? (g.out_w * C + K::NT - 1) / K::NT : 0;
     // Measured (config 2, ms per step riding / separate): 1 frame 0.0198 / 0.0253, 2: 0.0281 / 0.0335, 4: 0.0464 / 0.0525,
     // 8: 0.0687 / 0.0729, 16: 0.117-0.120 / 0.114-0.116 -- past about one prefix workgroup per CU they slow the march
@@ -1152,31 +1329,29 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
             ride_attr_done[exact][dev] = true;
         }
         if (exact)
-            hipLaunchKernelGGL((k_march<T, C, S, A, true, false, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc, chunk_rows);
+            hipLaunchKernelGGL((k_march<T, C, S, A, true, false, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
         else
             hipLaunchKernelGGL((k_march<T, C, S, A, false, false, true>), grid, dim3(K::NT), K::LDS_BYTES + extra_lds, stream, g, t,
-                               fc, chunk_rows);
+                               fc);
         return hipGetLastError();
     }
     if (exact)
-        hipLaunchKernelGGL((k_march<T, C, S, A, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc, chunk_rows);
+        hipLaunchKernelGGL((k_march<T, C, S, A, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
     else if (g.stamps && sizeof(T) == 1 && C == 3 && S == 2 && A == 3) {  // diagnostic build, one configuration
         using KS = MarchCfg<uint8_t, 3, 2, 3>;
-        hipLaunchKernelGGL((k_march<uint8_t, 3, 2, 3, false, true>), grid, dim3(KS::NT), KS::LDS_BYTES, stream, g, t, fc,
-                           chunk_rows);
+        hipLaunchKernelGGL((k_march<uint8_t, 3, 2, 3, false, true>), grid, dim3(KS::NT), KS::LDS_BYTES, stream, g, t, fc);
     }
     else
-        hipLaunchKernelGGL((k_march<T, C, S, A, false>), grid, dim3(K::NT), K::LDS_BYTES + extra_lds, stream, g, t, fc,
-                           chunk_rows);
+        hipLaunchKernelGGL((k_march<T, C, S, A, false>), grid, dim3(K::NT), K::LDS_BYTES + extra_lds, stream, g, t, fc);
     return hipGetLastError();
 }
 
 inline hipError_t march_launch(const lanczos_desc& d, const FrameGeom& g, const TapTables& t, const FastConsts& fc,
-                               hipStream_t stream, bool* prefix_fused, bool query_only = false) {
+                               hipStream_t stream, bool* prefix_fused, WgTabCache* cache, bool query_only = false) {
     *prefix_fused = false;
 #define X(T, C, S, A)                                                                               \
     if (d.bytes_per_sample == (int)sizeof(T) && d.channels == C && d.scale_n == S && d.a == A)      \
-        return march_launch_t<T, C, S, A>(d, g, t, fc, stream, prefix_fused, query_only);
+        return march_launch_t<T, C, S, A>(d, g, t, fc, stream, prefix_fused, query_only, cache);
     LZ_FAST_CONFIGS(X)
 #undef X
     return hipErrorNotSupported;

@@ -320,6 +320,31 @@ def test_full_size_config2_against_oracle(ctx, pattern):
     _cmp(got[0], want, L.MODE_LSB1, f"full-size {pattern} in a batch")
 
 
+@pytest.mark.parametrize("shape", [(1920, 1080, 3, 2, 1, 3, 16), (1920, 1080, 3, 2, 1, 3, 32), (1920, 1080, 3, 2, 1, 3, 24),
+                                   (1280, 720, 3, 3, 1, 3, 16), (1280, 720, 3, 3, 1, 3, 32)])
+def test_benchmark_batches_every_frame(ctx, shape):
+    """The launch shapes bench.py times (BASELINE configs 2 / 3 as batches of 16-32 frames): the marching kernel cuts them
+    into one workgroup per CU slot with RANK-AWARE shares (unequal chunks per strip, lanczos_march.hpp: march_build_table).
+    Every frame of the batch is the same picture, so every frame must equal frame 0 -- any gap or overlap in the partition
+    shows -- and frame 0 must carry the reference's known-answer digest in EXACT mode / stay within 1 LSB
+    of it in the default mode."""
+    iw, ih, c, sn, sd, a, frames = shape
+    with open(os.path.join(GOLD, "kat_digests.json")) as f:
+        kat = json.load(f)
+    planar = O.lcg_u8(c * ih * iw, 12345).reshape(c, ih, iw)
+    img = np.ascontiguousarray(planar.transpose(1, 2, 0))
+    batch = np.ascontiguousarray(np.broadcast_to(img, (frames,) + img.shape))
+    exact = ctx.resample(batch, sn, sd, a, L.MODE_EXACT)
+    dig = O.fnv1a64(np.ascontiguousarray(exact[0].transpose(2, 0, 1)))
+    assert f"{dig:016x}" == kat["survey_8c"][f"{iw}x{ih}_{iw * sn // sd}x{ih * sn // sd}_{sn}-{sd}_a{a}_c{c}"]
+    for i in range(1, frames):
+        assert np.array_equal(exact[i], exact[0]), f"EXACT: frame {i} of {frames} differs from frame 0"
+    fast = ctx.resample(batch, sn, sd, a, L.MODE_LSB1)
+    assert np.abs(fast[0].astype(np.int16) - exact[0].astype(np.int16)).max() <= 1
+    for i in range(1, frames):
+        assert np.array_equal(fast[i], fast[0]), f"LSB1: frame {i} of {frames} differs from frame 0"
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE config 5 at FULL size: 3840x2160x4 uint16 -> 7680x4320, a = 4.  PARITY UNPINNED BY THE REFERENCE (it has no
 # 16-bit path, full_TB.h:18,30): the checker is the restatement templated on the sample type (clamp 65535).
