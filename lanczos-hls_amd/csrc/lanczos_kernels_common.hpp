@@ -39,7 +39,8 @@ struct FrameGeom {
     // k_prefix); prefix_K == 0: a separate k_prefix launch does that
     int n_main, wg_per_frame, prefix_blocks_per_frame, prefix_K, prefix_M, prefix_M2;
     int debug_skip;       // ablation bits for profiling builds (0 in production): 1 H-pass, 2 fix-up, 4 V-pass, 8 stores, 16 loads
-    const WgEntry* wg_tab; // k_march only: [n_main] share of every marching workgroup, indexed by the hardware block id
+    const WgEntry* wg_tab; // k_march only: [n_main][wg_segs] share of every marching workgroup, indexed by the hardware block id
+    int wg_segs;           // segments (table entries) per workgroup
 };
 
 struct TapTables {

@@ -239,12 +239,12 @@ struct MarchCfg {
 #endif
     // per-lane indices rebuilt every tick from an opaque copy of the thread id instead of living in registers across the
     // phases (what the RIDE variant does): configurations that sit just above an occupancy step
-#if defined(LZ_MARCH_OPAQUE_ALL)
-    static constexpr bool OPAQUE_IDX = true;
-#elif defined(LZ_MARCH_C3_OPAQUE)
-    static constexpr bool OPAQUE_IDX = SB == 1 && C == 3 && S == 3;
-#else
+    // (default since the march became a loop over segments: with the indices held across that loop config 2 needs 81 VGPRs
+    // -- three workgroups per CU, 310 us instead of 210 --, rebuilt per tick 68; the rebuild itself measured neutral)
+#if defined(LZ_MARCH_NO_OPAQUE)
     static constexpr bool OPAQUE_IDX = false;
+#else
+    static constexpr bool OPAQUE_IDX = true;
 #endif
     static constexpr int MIN_WAVES = SPLIT ? LZ_MARCH_MIN_WAVES : ((SB == 1 && C == 3 && S == 3) ? LZ_MARCH_C3_MINW : 1);
     static_assert(MS % NGRP == 0, "V groups split a tick evenly");
@@ -351,29 +351,42 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     //     workgroup on its CU) and the SIMD arbiter serves older waves first: with equal shares the 1st..4th workgroup of a CU
     //     took 179 / 189 / 197 / 207 us, the three of a CU that got only three 152 / 164 / 179 us, and the launch ended in a
     //     70 us tail of half-empty CUs (profiles/round2e_census_32frames.txt).  The table gives faster slots more rows.
-    const WgEntry we = g.wg_tab[blockIdx.x];  // uniform: scalar loads
-    const int frame = we.frame, tx = we.tx, m_b = we.m_b, m_e = we.m_e;
-
-    // rows: m = floor(y/S) is the input row an output row hangs on.  This workgroup owns m in [m_b, m_e).
+    // A workgroup's share is up to g.wg_segs SEGMENTS (consecutive table entries; m_b >= m_e: empty): with one workgroup per CU
+    // slot a share may run from the end of one (strip, frame) pair into the start of the next.  Everything below that depends
+    // on the segment is a plain variable the lambdas capture by reference; load_segment() sets them.
     const int y_lo = g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows;  // first output row stored at all
     const int y_hi = g.out_row0 + g.out_rows;                               // one past the last
-    if (m_b >= m_e) return;
-    const int hb = m_b - (A - 1);           // first H row (= input row) this chunk needs
-    const int h_last = m_e - 1 + A;         // last one
-    const int ticks = (h_last - hb + 1 + K::MS - 1) / K::MS;
-
-    const int P0 = tx * F::TWP_IN;          // first input pixel owned by the strip
     const int row_bytes = g.in_w * C * SB;
-    const uint8_t* in_f = g.in + (size_t)frame * g.in_frame_stride;
-    uint8_t* out_f = g.out + (size_t)frame * g.out_frame_stride;
     const int gr_min = g.in_row0 > 0 ? g.in_row0 : 0;
     const int gr_max = (g.in_row0 + g.in_rows < g.in_h ? g.in_row0 + g.in_rows : g.in_h) - 1;
-    const int tile_gb0 = P0 * C * SB - F::LPB;  // byte offset in the input row of LDS column 0
-
+    // rows: m = floor(y/S) is the input row an output row hangs on.  The segment owns m in [m_b, m_e).
+    int tx = 0, m_b = 0, m_e = 0;
+    int hb = 0;      // first H row (= input row) the segment needs
+    int h_last = 0;  // last one
+    int ticks = 0;
+    int tile_gb0 = 0;  // byte offset in the input row of LDS column 0
     // ---- input rows of one tick -> registers -> LDS.  Rows are 16-byte multiples (checked on the host), so a
     // chunk is never partly inside the image; outside lanes get an out-of-range offset and read zeros.
-    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(in_f), 0, (unsigned)(g.in_rows * g.in_pitch), 0x00020000);
+    __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(g.in), 0, (unsigned)(g.in_rows * g.in_pitch), 0x00020000);
+    __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (unsigned)(g.out_rows * g.out_pitch), 0x00020000);
+    auto load_segment = [&](int seg) -> bool {  // uniform
+        const WgEntry we = g.wg_tab[(size_t)blockIdx.x * g.wg_segs + seg];  // scalar loads
+        // (readfirstlane: inside the segment loop the compiler no longer proves these uniform by itself, and everything
+        // derived from them -- row counters, the buffer descriptors -- would move into vector registers: 72 -> 83 VGPRs)
+        const int frame = __builtin_amdgcn_readfirstlane(we.frame);
+        tx = __builtin_amdgcn_readfirstlane(we.tx), m_b = __builtin_amdgcn_readfirstlane(we.m_b), m_e = __builtin_amdgcn_readfirstlane(we.m_e);
+        if (m_b >= m_e) return false;
+        hb = m_b - (A - 1);
+        h_last = m_e - 1 + A;
+        ticks = (h_last - hb + 1 + K::MS - 1) / K::MS;
+        tile_gb0 = tx * F::TWP_IN * C * SB - F::LPB;
+        irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(g.in + (size_t)frame * g.in_frame_stride), 0,
+                                                  (unsigned)(g.in_rows * g.in_pitch), 0x00020000);
+        orsrc = __builtin_amdgcn_make_buffer_rsrc(g.out + (size_t)frame * g.out_frame_stride, 0,
+                                                  (unsigned)(g.out_rows * g.out_pitch), 0x00020000);
+        return true;
+    };
+
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 pre[K::LOAD_IT];
     // (RIDE: per-lane indices are rebuilt every tick from an opaque copy of the thread id -- a handful of instructions --
@@ -739,8 +752,6 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
 
     // =================================================================== VPASS of one tick
     const int grp_w = K::NGRP == 1 ? 0 : wave * 64 / K::NVT_PAD;  // the wave's V group (NGRP > 1: groups are whole waves)
-    const __amdgpu_buffer_rsrc_t orsrc =
-        __builtin_amdgcn_make_buffer_rsrc(out_f, 0, (unsigned)(g.out_rows * g.out_pitch), 0x00020000);
     float vbias = (SB == 1 && !EXACT) ? (K::SYM ? fc.vbias_rne_p : fc.vbias_rne) : (K::SYM ? fc.bias_p : fc.bias);
     asm volatile("" : "+v"(vbias));
 
@@ -913,7 +924,15 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     }
     if (tid < kFastMaxS * kMaxTaps)  // exact-chain phase weights (published by the prologue's first barrier)
         ((double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL + K::LDS_HW))[tid] = t.x_w[tid];
-    if (K::LDS_HW > 0) {  // the strip's slice of the horizontal tap table (published by the prologue's first barrier)
+    // =================================================================== the march, segment by segment
+    unsigned long long tsum[5] = {0, 0, 0, 0, 0};  // diagnostic build only (STAMP): where a wave's cycles go
+    int ticks_total = 0;
+#pragma clang loop unroll(disable)
+    for (int seg = 0; seg < g.wg_segs; seg++) {
+    if (!load_segment(seg)) continue;  // uniform
+    ticks_total += ticks;
+    if (K::LDS_HW > 0) {  // the strip's slice of the horizontal tap table (published by the prologue's first barrier; every wave
+                          // has left the previous segment's last barrier, nobody reads the old slice any more)
         double* hwl = (double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL);
         for (int i = tid; i < F::TWP_OUT * TAPS; i += K::NT) {
             int xx = tx * F::TWP_OUT + i / TAPS;
@@ -921,7 +940,6 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
             hwl[i] = t.h_w[(size_t)xx * TAPS + i % TAPS];
         }
     }
-    // =================================================================== the march
     if (K::SPLIT) {
         // Role-specialised waves.  Both roles pass the same barriers (one after the prologue's loads, one after H(0), one
         // per tick); between two barriers the H waves produce tick t+1's rows in the ring while the V waves consume tick
@@ -951,7 +969,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                 __syncthreads();
             }
         }
-        return;
+        continue;
     }
     if (K::LDSDMA) {
         issue_loads(0);
@@ -969,8 +987,6 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     __syncthreads();
     hpass(0);
     __syncthreads();
-    // diagnostic build only (STAMP): where a wave's cycles go, summed over the march, written once at the end
-    unsigned long long tsum[5] = {0, 0, 0, 0, 0};
     auto stamp = [&]() -> unsigned long long {
         unsigned long long tt = 0;
         if (STAMP) {
@@ -1012,10 +1028,11 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
             tsum[0] += t1 - t0; tsum[1] += t2 - t1; tsum[2] += t3 - t2; tsum[3] += t4 - t3; tsum[4] += t5 - t4;
         }
     }
+    }  // segments
     if (STAMP && g.stamps && lane == 0) {
         unsigned long long* dst = g.stamps + ((size_t)blockIdx.x * K::NWAVES + wave) * 6;
         for (int i = 0; i < 5; i++) dst[i] = tsum[i];
-        dst[5] = (unsigned long long)ticks;
+        dst[5] = (unsigned long long)ticks_total;
         if (wave == 0) {  // second half of the buffer: one record per workgroup
             unsigned long long* c = g.stamps + (size_t)16384 * 8 * 3 + (size_t)blockIdx.x * 3;
             c[0] = census_t0;
@@ -1116,27 +1133,101 @@ inline int march_align_rows(int rows, int ms, int taps) {
     return t * ms - (taps - 1);
 }
 
-// Fills `tab` (indexed by hardware block id) for `strips` x `frames` pairs whose rows [m_lo, m_hi) are cut into chunks.
-// Returns the number of marching workgroups.
-inline int march_build_table(std::vector<WgEntry>& tab, int strips, int frames, int m_lo, int m_hi, int ms, int taps, int nb,
-                             int cus, int nwaves, bool* balanced_out) {
+// Fills `tab` ([block id][segs]) for `strips` x `frames` pairs whose rows [m_lo, m_hi) are shared out among the marching
+// workgroups.  Returns the number of marching workgroups; *segs_out = table entries per workgroup.
+//   mode A (large batches): exactly one workgroup per CU slot.  The pairs are dealt to the XCDs in consecutive runs (neighbouring
+//     strips share an L2); inside an XCD the pairs' rows form one line that is cut into consecutive shares proportional to
+//     the slots' speeds.  A share may run from one pair into the next: up to 3 segments, cuts moved off pair boundaries'
+//     neighbourhood and onto tick boundaries.
+//   mode B: whole chunks (one segment), equal, or -- one resident round of >= 2 chunks per pair -- fast slots paired with
+//     slow ones and the pair's rows split by speed.
+inline int march_build_table(std::vector<WgEntry>& tab, int* segs_out, int strips, int frames, int m_lo, int m_hi, int ms, int taps,
+                             int nb, int cus, int nwaves, bool* balanced_out) {
     const int m_rows = m_hi - m_lo, slots = nb * cus, pairs = strips * frames;
+    const int nx = 8, cu_x = cus / nx > 0 ? cus / nx : 1;
+    const MarchSlotSpeed sp = march_slot_speed(nb, nwaves);
+    static const int segs_env = getenv("LANCZOS_MARCH_SEGS") ? atoi(getenv("LANCZOS_MARCH_SEGS")) : -1;  // 0: never mode A
+    const int ticks_pair = (m_rows + taps - 1 + ms - 1) / ms;
+    // what mode B would do with this shape
     const int rows_u = march_chunk_rows(m_rows, strips, frames, ms, slots, taps);
     const int chunks = (m_rows + rows_u - 1) / rows_u;
-    const int n = pairs * chunks;
-    tab.assign(n, WgEntry{0, 0, 0, 0});
-    const int nx = 8, cu_x = cus / nx > 0 ? cus / nx : 1;
-    // pairs (frame-major: neighbouring strips consecutive) are dealt to the XCDs in consecutive runs; XCD x owns the
-    // hardware ids x, x + 8, ...: (n - x + 7) / 8 of them
-    const MarchSlotSpeed sp = march_slot_speed(nb, nwaves);
-    bool balanced = n <= slots && chunks >= 2 && cus % nx == 0;
-    for (int x = 0; x < nx && balanced; x++)
-        if (((n - x + nx - 1) / nx) % chunks != 0) balanced = false;
-    if (balanced) {
+    const int n_b = pairs * chunks;
+    bool b_balanced = n_b <= slots && chunks >= 2 && cus % nx == 0;
+    for (int x = 0; x < nx && b_balanced; x++)
+        if (((n_b - x + nx - 1) / nx) % chunks != 0) b_balanced = false;
+    if (b_balanced) {
         bool any = false;
         for (int i = 0; i < 8; i++) any = any || sp.full[i] != 1.0 || sp.shorty[i] != 1.0;
-        balanced = any;
+        b_balanced = any;
     }
+    // Mode B keeps the strips of a frame on the same rows at the same time (their 384-byte input segments are one
+    // 5760-byte image row: the DRAM sees whole rows) and wins where it fills the machine in one balanced round (config 2,
+    // 32 frames: 217 us against 232 for mode A); mode A wins where B would need two rounds or leave slots empty
+    // (config 3, 32 frames: 245 -> 235 us; config 5, 8 frames: 633 -> 621).
+    const bool b_good = b_balanced && n_b * 10 >= slots * 9;
+    // ---------------------------------------------------------------- mode A
+    if (segs_env != 0 && (!b_good || segs_env > 0) && cus % nx == 0 && pairs >= 8 * nx && (pairs % nx == 0 || pairs >= 32 * nx) &&
+        (long)pairs * ticks_pair >= (long)slots * 10 && pairs <= 2 * slots - 2 * nx) {
+        const int n = slots, n_x = slots / nx, min_seg = 3 * ms - (taps - 1);
+        std::vector<std::vector<WgEntry>> share(n);
+        int pair0 = 0, max_segs = 1;
+        for (int x = 0; x < nx; x++) {
+            const int np = pairs / nx + (x < pairs % nx ? 1 : 0);
+            const long R = (long)np * m_rows;
+            double tot = 0;
+            for (int j = 0; j < n_x; j++) tot += (j / cu_x < 8) ? sp.full[j / cu_x] : 1.0;
+            long prev = 0;  // start of the current share on the XCD's line of rows
+            double acc = 0;
+            for (int j = 0; j < n_x; j++) {
+                acc += (j / cu_x < 8) ? sp.full[j / cu_x] : 1.0;
+                long cut = j + 1 == n_x ? R : (long)(R * (acc / tot) + 0.5);
+                if (cut < prev) cut = prev;
+                if (j + 1 < n_x) {
+                    const long q = cut / m_rows;
+                    long r = cut - q * m_rows;
+                    if (r < min_seg) r = 0;                                  // no sliver at the top of a pair ...
+                    else if (m_rows - r < min_seg) r = m_rows;               // ... nor at its bottom
+                    else {
+                        // the segment that ends here starts at the share's start or at the pair's top: make it whole ticks
+                        const long seg0 = prev > q * m_rows ? prev - q * m_rows : 0;
+                        long len = r - seg0;
+                        long t = (len + taps - 1 + ms / 2) / ms;
+                        if (t < 3) t = 3;
+                        r = seg0 + t * ms - (taps - 1);
+                        if (m_rows - r < min_seg) r = m_rows;
+                    }
+                    cut = q * m_rows + r;
+                    if (cut < prev) cut = prev;
+                    if (cut > R) cut = R;
+                }
+                // [prev, cut) -> segments
+                std::vector<WgEntry>& sh = share[(size_t)j * nx + x];
+                for (long pos = prev; pos < cut;) {
+                    const long q = pos / m_rows, r0 = pos - q * m_rows;
+                    const long r1 = (cut - q * m_rows) < m_rows ? (cut - q * m_rows) : m_rows;
+                    const int pair = pair0 + (int)q;
+                    sh.push_back(WgEntry{pair / strips, pair % strips, m_lo + (int)r0, m_lo + (int)r1});
+                    pos = q * m_rows + r1;
+                }
+                if ((int)sh.size() > max_segs) max_segs = (int)sh.size();
+                prev = cut;
+            }
+            pair0 += np;
+        }
+        tab.assign((size_t)n * max_segs, WgEntry{0, 0, 0, 0});
+        for (int b = 0; b < n; b++)
+            for (size_t k = 0; k < share[b].size(); k++) tab[(size_t)b * max_segs + k] = share[b][k];
+        *segs_out = max_segs;
+        *balanced_out = true;
+        return n;
+    }
+    // ---------------------------------------------------------------- mode B
+    *segs_out = 1;
+    const int n = n_b;
+    tab.assign(n, WgEntry{0, 0, 0, 0});
+    // pairs (frame-major: neighbouring strips consecutive) are dealt to the XCDs in consecutive runs; XCD x owns the
+    // hardware ids x, x + 8, ...: (n - x + 7) / 8 of them
+    const bool balanced = b_balanced;
     *balanced_out = balanced;
     int pair0 = 0, lid0 = 0;
     for (int x = 0; x < nx; x++) {
@@ -1202,7 +1293,7 @@ struct WgTabCache {
     struct Item {
         long long key[8];
         WgEntry* dev;
-        int n;
+        int n, segs;
         bool balanced;
     };
     std::vector<Item> items;
@@ -1266,14 +1357,16 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     if (!item) {
         std::vector<WgEntry> tab;
         bool balanced = false;
-        const int n = march_build_table(tab, strips, g.frames, m_lo, m_hi, K::MS, K::TAPS, nb_, cus_of[dev_], K::NWAVES, &balanced);
+        int segs = 1;
+        const int n = march_build_table(tab, &segs, strips, g.frames, m_lo, m_hi, K::MS, K::TAPS, nb_, cus_of[dev_], K::NWAVES, &balanced);
         WgTabCache::Item it;
         memcpy(it.key, key, sizeof(key));
         it.n = n;
+        it.segs = segs;
         it.balanced = balanced;
         it.dev = nullptr;
-        hipError_t e = hipMalloc(&it.dev, sizeof(WgEntry) * (size_t)n);
-        if (e == hipSuccess) e = hipMemcpy(it.dev, tab.data(), sizeof(WgEntry) * (size_t)n, hipMemcpyHostToDevice);
+        hipError_t e = hipMalloc(&it.dev, sizeof(WgEntry) * tab.size());
+        if (e == hipSuccess) e = hipMemcpy(it.dev, tab.data(), sizeof(WgEntry) * tab.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) return e;
         if (cache->items.size() >= 64) {  // bounded: drop the oldest shape (nothing in flight uses it once its stream has drained)
             (void)hipDeviceSynchronize();
@@ -1283,10 +1376,11 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
         cache->items.push_back(it);
         item = &cache->items.back();
         if (getenv("LANCZOS_VERBOSE"))
-            fprintf(stderr, "lanczos: k_march table: %d workgroups for %d strips x %d frames, rows [%d, %d): %s shares\n", n, strips,
-                    g.frames, m_lo, m_hi, balanced ? "rank-aware" : "equal");
+            fprintf(stderr, "lanczos: k_march table: %d workgroups x %d segment(s) for %d strips x %d frames, rows [%d, %d): %s shares\n", n,
+                    segs, strips, g.frames, m_lo, m_hi, balanced ? "rank-aware" : "equal");
     }
     g.wg_tab = item->dev;
+    g.wg_segs = item->segs;
     g.wg_per_frame = 0;
     g.n_main = item->n;
     g.prefix_blocks_per_frame = g.prefix_K > 0 ? (g.out_w * C + K::NT - 1) / K::NT : 0;
