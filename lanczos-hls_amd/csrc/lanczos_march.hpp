@@ -1252,11 +1252,55 @@ inline int march_build_table(std::vector<WgEntry>& tab, int* segs_out, int strip
             if (rank < 8) v = on_cu >= nb ? sp.full[rank] : (on_cu == nb - 1 ? sp.shorty[rank] : 1.0);
             sj[j] = {v, j};
         }
+        const int groups = n_x / chunks;
+        static const int band_sync = getenv("LANCZOS_BAND_SYNC") ? atoi(getenv("LANCZOS_BAND_SYNC")) : 0;
+        if (band_sync && groups % strips == 0) {
+            // Band-synchronous shares: the `strips` workgroups of one (frame, chunk) band sit on consecutive slots (mostly one
+            // rank) and ALL get the same rows, so that the strips of a frame stay on the same image rows at the same time;
+            // fast bands are paired with slow ones frame by frame.
+            const int runs = n_x / strips, frames_x = groups / strips;
+            std::vector<std::pair<double, int>> rs(runs);
+            for (int r = 0; r < runs; r++) {
+                double v = 0;
+                for (int k = 0; k < strips; k++) v += sj[r * strips + k].first;
+                rs[r] = {v / strips, r};
+            }
+            std::sort(rs.begin(), rs.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
+                return a.first != b.first ? a.first > b.first : a.second < b.second;
+            });
+            std::vector<std::vector<std::pair<double, int>>> fg(frames_x);
+            for (int i = 0; i < runs; i++) {
+                const int round = i / frames_x, pos = i % frames_x;
+                fg[(round & 1) ? frames_x - 1 - pos : pos].push_back(rs[i]);
+            }
+            for (int fi = 0; fi < frames_x; fi++) {
+                auto& mem = fg[fi];
+                std::sort(mem.begin(), mem.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.second < b.second; });
+                double tot = 0;
+                for (auto& m : mem) tot += m.first;
+                const int frame = (pair0 + fi * strips) / strips;
+                int b = m_lo;
+                double acc = 0;
+                for (size_t k = 0; k < mem.size(); k++) {
+                    acc += mem[k].first;
+                    int e;
+                    if (k + 1 == mem.size()) e = m_hi;
+                    else {
+                        const int want = (int)(m_lo + m_rows * acc / tot + 0.5) - b;
+                        e = b + march_align_rows(want, ms, taps);
+                        if (e > m_hi) e = m_hi;
+                    }
+                    for (int tx = 0; tx < strips; tx++) tab[(size_t)(mem[k].second * strips + tx) * nx + x] = WgEntry{frame, tx, b, e};
+                    b = e;
+                }
+            }
+            pair0 += groups;
+            continue;
+        }
         std::sort(sj.begin(), sj.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
             return a.first != b.first ? a.first > b.first : a.second < b.second;
         });
         // groups of `chunks` slots with near-equal speed sums: deal the sorted slots out in snake order
-        const int groups = n_x / chunks;
         std::vector<std::vector<std::pair<double, int>>> grp(groups);
         for (int i = 0; i < n_x; i++) {
             const int round = i / groups, pos = i % groups;
