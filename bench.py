@@ -72,7 +72,7 @@ def csrc_fingerprint():
 # prologue (two input ticks, the window rows) and every step a prefix launch: measured 16 frames 102-104 us per step,
 # 32 frames 199 us (6.2 us per frame against 6.4), 8 frames 60 us.  The 16- and 8-frame steps are reported under
 # other_batches.
-DEFAULT_FRAMES = {"c1": 32, "c2": 32, "c3": 24, "c5": 8}
+DEFAULT_FRAMES = {"c1": 32, "c2": 32, "c3": 32, "c5": 8}
 
 
 def make_frames(torch, pattern, frames, h, w, c, bps, device, seed):

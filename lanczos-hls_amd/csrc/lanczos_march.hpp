@@ -162,13 +162,15 @@ struct MarchCfg {
     static constexpr int LDS_TIN = 2 * TIN_BYTES;                    // double buffered
     static constexpr int LDS_HBUF = RS * H_PITCH;
     static constexpr int LDS_WL = NLISTS * WLW * 2;
-    // scales whose per-index double weights are not the phase weights bit for bit (S = 3: x = xx / 3.0 is rounded) keep the
-    // strip's slice of the horizontal tap table in LDS: a fix-up that gathers 6 doubles from global memory holds its
-    // workgroup's barrier for a memory round trip (measured on config 3: near-integer fix-ups 33 of 158 us)
-#ifdef LZ_MARCH_NO_HW_LDS
-    static constexpr int LDS_HW = 0;
-#else
+    // Scales whose per-index double weights are not the phase weights bit for bit (S = 3: x = xx / 3.0 is rounded) read them
+    // from the global tap table in the (rare) fix-up.  Round 2 first kept the strip's slice of that table in LDS (18 KiB): a
+    // fix-up that gathered 6 doubles from global memory held its workgroup's barrier for a memory round trip (33 of 158 us on
+    // config 3).  Since the event path was shortened the slice buys nothing (121 vs 120 us) and costs the THIRD workgroup per
+    // CU: without it config 3 runs 178 -> 161 us at 24 frames, 235 -> 209 at 32 (-DLZ_MARCH_HW_LDS brings it back).
+#ifdef LZ_MARCH_HW_LDS
     static constexpr int LDS_HW = (S == 3) ? F::TWP_OUT * TAPS * 8 : 0;
+#else
+    static constexpr int LDS_HW = 0;
 #endif
     // the exact chain's phase weights (TapTables::x_w: integer phase + S-1 interior phases, 256 B): a fix-up that fetches them
     // from global memory holds its workgroup's barrier for a memory round trip
