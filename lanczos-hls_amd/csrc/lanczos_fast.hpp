@@ -49,6 +49,8 @@ struct FastConsts {
     int skip_last;                  // 1: the last integer-phase tap (x - i = -a, ~1e-33) can never change the sum
     int tight;                      // 1: the only non-negligible negative integer-phase taps sit at +-2 pixels and
                                     //    are < 2^-55, so neighbours <= 2*v0 prove that v0 stays (see fast_prepare)
+    int tight2;                     // 1: additionally the +-1 taps are positive and twice the +-2 taps and half the spacing
+                                    //    below v0 is >= 3.4 v0 |L(2)|: the second-stage filter of k_march applies
 };
 
 // per-configuration tile shape: MR input rows advanced per tile, NGRP vertical thread groups in the V pass
@@ -558,6 +560,7 @@ inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTap
     if (fc->vlim >= (d.bytes_per_sample == 1 ? 126 : 32766)) return false;  // SWAR test needs vlim < half range
     // Tight filter precondition (integer_phase_tight, lanczos_taps.cpp)
     fc->tight = integer_phase_tight(fc->wi, a, maxv) ? 1 : 0;
+    fc->tight2 = (fc->tight && d.bytes_per_sample == 1 && integer_phase_tight2(fc->wi, a, fc->vlim)) ? 1 : 0;
     // Integer-phase chain, last tap (x - i = -a): by then the running sum is v0 +- a few ulp >= 0.5, so its spacing is
     // >= 2^-54; a term below 2^-55 cannot move it (strictly less than half the spacing: no tie either).  The centre
     // weight is exactly 1.0 (sinc(0)*sinc(0)), so that product is the sample itself.

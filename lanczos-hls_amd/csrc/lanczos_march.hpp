@@ -642,6 +642,49 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         const uint32_t tight = loose[i] & ~(pm & pp) & TOP;
                         im |= (tight >> (8 * SB - 1)) << i;
                     }
+                    // Second stage (8-bit samples, fc.tight2 = preconditions checked in fast_prepare): a flip of v0 also needs
+                    //     n(-2) > 2 n(-1) + 3 v0    or    ( n(+2) > 3 v0  and  n(+2) + 4 v0 + 2 > 2 n(+1) )
+                    // (the +-1 taps are positive and twice the +-2 taps; derivation: DESIGN.md 3, exhaustive check:
+                    // tests/test_integer_phase_filter.py).  On noise this takes the candidates from 23 % of the integer-phase
+                    // samples to 8 %; evaluated on 16-bit lanes (even / odd bytes), only in waves that still hold a candidate.
+                    // MEASURED (profiles/round2h_ab_second_stage_filter.txt, outputs identical): the ~170 VALU instructions per
+                    // unit cost more than the fix-ups they save -- noise 326 -> 345 us on config 2, 260 -> 268 on config 3,
+                    // gradient / blocks unchanged -- so the stage is compiled in only with -DLZ_MARCH_TIGHT2.
+#ifdef LZ_MARCH_TIGHT2
+                    constexpr bool kTight2 = true;
+#else
+                    constexpr bool kTight2 = false;
+#endif
+                    if (kTight2 && SB == 1 && A >= 3 && fc.tight2 && __any(im != 0)) {
+                        uint32_t im2 = 0;
+#pragma unroll
+                        for (int i = 0; i < F::UNIT_IN_DW; i++) {
+                            auto window_word = [&](int bo) -> uint32_t {
+                                return (bo & 3) == 0 ? wd[bo >> 2]
+                                                     : __builtin_amdgcn_alignbyte(wd[(bo >> 2) + 1], wd[bo >> 2], bo & 3);
+                            };
+                            const uint32_t w0 = wd[OWN_DW0 + i];
+                            const uint32_t wm2 = window_word(OWN_B0 + 4 * i - 2 * C), wm1 = window_word(OWN_B0 + 4 * i - C);
+                            const uint32_t wp1 = window_word(OWN_B0 + 4 * i + C), wp2 = window_word(OWN_B0 + 4 * i + 2 * C);
+                            constexpr uint32_t M = 0x00ff00ffu, B15 = 0x80008000u;
+                            uint32_t keep = 0;
+#pragma unroll
+                            for (int h = 0; h < 2; h++) {  // h = 0: bytes 0 and 2, h = 1: bytes 1 and 3 -- one 16-bit lane each
+                                const uint32_t X = (w0 >> (8 * h)) & M, N2m = (wm2 >> (8 * h)) & M, N1m = (wm1 >> (8 * h)) & M;
+                                const uint32_t N1p = (wp1 >> (8 * h)) & M, N2p = (wp2 >> (8 * h)) & M;
+                                const uint32_t V3 = X + (X << 1);
+                                // bit 15 of a lane is SET when the quantity is >= 0 (bias 0x8000, no lane ever borrows or overflows:
+                                // every quantity lies within +-1 300)
+                                const uint32_t tA = (N1m << 1) + V3 + B15 - N2m;                    // 2 n(-1) + 3 v0 - n(-2)
+                                const uint32_t t1 = V3 + B15 - N2p;                                 // 3 v0 - n(+2)
+                                const uint32_t t2 = (N1p << 1) + B15 - N2p - (X << 2) - 0x00020002u;  // 2 n(+1) - n(+2) - 4 v0 - 2
+                                const uint32_t cand = ~(tA & (t1 | t2)) & B15;  // A violated, or both B conditions violated
+                                keep |= h == 0 ? (cand >> 8) : cand;            // back to the byte lanes' top bits
+                            }
+                            im2 |= (keep >> 7) << i;
+                        }
+                        im &= im2;
+                    }
                 }
             }
         }

@@ -160,6 +160,39 @@ bool integer_phase_tight(const double* wi, int a, double maxv) {
     return ok;
 }
 
+bool integer_phase_tight2(const double* wi, int a, int vlim) {
+    // Preconditions of the second-stage filter (integer_phase_tight already holds: negative taps only at +-2, < 2^-55).
+    // The double chain of an integer phase is  s = (((t(-a+1..-3)) + n(-2) w(2)) + n(-1) w(1)) + v0 + n(+1) w(-1) + n(+2) w(-2) + ...
+    // with every rounding monotone.  With l2 = |w(+-2)|, l1 = w(+-1) = 2 l2 (1 + d), hb(v0) = half the spacing below v0:
+    //   A-safe : n(-2) <= 2 n(-1) + 3 v0   =>  the tiny sum in front of v0 is >= -hb         => the sum is >= v0 after v0
+    //   B-safe1: n(+2) <= 3 v0             =>  n(+2) l2 <= hb                                 => it cannot pull a sum >= v0 below v0
+    //   B-safe2: n(+2) + 4 v0 + 2 <= 2 n(+1)  =>  n(+2) l2 <= n(+1) l1 - ulp(v0)/2 + hb       => the same after n(+1)'s push
+    // (a tie lands on v0, whose mantissa is even).  A flip therefore needs  not A-safe  or  (not B-safe1 and not B-safe2).
+    // Needed: both +-2 taps equal, both +-1 taps equal and positive, |l1 / l2 - 2| < 1e-6 (it is ~1e-16), every other tap
+    // (|d| >= 3) non-negative or negligible, and hb(v0) >= 3.4 v0 l2 for all v0 <= vlim (it is 3.44 v0 l2 at powers of two).
+    if (a < 3 || vlim < 1 || vlim > 85) return false;  // 3 v0 and 4 v0 + 2 n must fit the 16-bit lanes comfortably
+    const int taps = 2 * a;
+    auto at = [&](int dist) { return wi[a - 1 - dist]; };  // tap of x - i = dist
+    const double l2 = -at(2), l1 = at(1);
+    if (!(l2 > 0 && l1 > 0) || at(-2) != at(2) || at(-1) != at(1) || at(0) != 1.0) return false;
+    if (std::fabs(l1 / l2 - 2.0) > 1e-6) return false;
+    for (int k = 0; k < taps; k++) {
+        const int dist = a - 1 - k;
+        if (dist >= -2 && dist <= 2) continue;
+        if (wi[k] < 0 && -wi[k] * 255.0 > std::ldexp(1.0, -70)) return false;
+    }
+    for (int v0 = 1; v0 <= vlim; v0++) {
+        const int e = std::ilogb((double)v0);
+        const bool pow2 = (v0 & (v0 - 1)) == 0;
+        const double hb = std::ldexp(1.0, pow2 ? e - 54 : e - 53);
+        if (!(hb >= 3.4 * v0 * l2 * (1.0 + 1e-9))) return false;
+        // B-safe2 at a power of two: n(+1)'s push is rounded down by up to ulp/2 = 2 hb, so n(+2) l2 <= n(+1) l1 - hb is
+        // needed, and "4 v0" stands for hb / l2 there
+        if (pow2 && !(hb <= 3.9 * v0 * l2)) return false;
+    }
+    return true;
+}
+
 int integer_phase_flip_limit(const double* wi, int a, int maxv) {
     // Lower-bound chain (rounding is monotone): drop the positive tiny terms.  The negative terms in
     // front of the centre accumulate to -nb; each negative term behind it is applied on its own.  If

@@ -64,5 +64,6 @@ int integer_phase_flip_limit(const double* wi, int a, int maxv);
 // +-2 samples and are < 2^-55 in magnitude.  Then a centre sample v0 whose +-2 neighbours are both <= 2*v0 provably
 // survives the double chain (the negative excursion stays below half the spacing under v0).
 bool integer_phase_tight(const double* wi, int a, double maxv);
+bool integer_phase_tight2(const double* wi, int a, int vlim);
 
 }  // namespace lz
