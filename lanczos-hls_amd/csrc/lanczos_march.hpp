@@ -797,7 +797,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
 
     // =================================================================== VPASS of one tick
     const int grp_w = K::NGRP == 1 ? 0 : wave * 64 / K::NVT_PAD;  // the wave's V group (NGRP > 1: groups are whole waves)
-    float vbias = (SB == 1 && !EXACT) ? (K::SYM ? fc.vbias_rne_p : fc.vbias_rne) : (K::SYM ? fc.bias_p : fc.bias);
+    float vbias = SB == 1 ? (K::SYM ? fc.vbias_rne_p : fc.vbias_rne) : (K::SYM ? fc.bias_p : fc.bias);
     asm volatile("" : "+v"(vbias));
 
     // SPLIT: the V window lives across ticks (the slot rotation realigns every MS = k * TAPS rows)
@@ -863,7 +863,19 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                     bool undecided = false;
                     if (ph == 0) {
                         packed = raw[(i + A - 1) % TAPS];
-                        if (EXACT && fc.vlim > 0) {
+                        if (EXACT && fc.vlim > 0 && SB == 1 && A >= 3 && fc.tight) {
+                            // the H pass's byte-parallel tests on the packed ring dwords: 1 <= v0 <= vlim (and only in
+                            // waves that hold such a sample at all) a row two above or below brighter than 2*v0
+                            const uint32_t x = packed, t7 = x & LOW;
+                            const uint32_t lo = ((t7 + LOW) | x) & ~((t7 + addc) | x) & TOP;
+                            if (__any(lo != 0)) {
+                                const uint32_t c2 = (t7 << 1) | TOP;
+                                const uint32_t nm = raw[(i + A - 3) % TAPS], np = raw[(i + A + 1) % TAPS];
+                                const uint32_t pm = (c2 - (nm & LOW)) & ~nm;   // top bit: row m-2 <= 2*v0
+                                const uint32_t pp = (c2 - (np & LOW)) & ~np;   // top bit: row m+2 <= 2*v0
+                                undecided = (lo & ~(pm & pp) & TOP) != 0;
+                            }
+                        } else if (EXACT && fc.vlim > 0) {
                             // the integer-phase chain can leave v0 only if 1 <= v0 <= vlim AND (fc.tight, proven in
                             // fast_prepare for these weights) a row two above or below is brighter than 2*v0 -- without
                             // the second test nearly every row of a natural image would take the f64 path
@@ -898,12 +910,21 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                             }
                             accs[e] = acc;
                         }
-                        if (SB == 1 && !EXACT) {
+                        if (SB == 1) {
                             // floor(sum + eps): the sum is biased by eps - 0.5 and the hardware's saturating
                             // round-to-nearest-even byte convert does the rest (a tie needs fract(sum+eps) == 0,
                             // an undecided sample, which is within 1 LSB either way)
 #pragma unroll
                             for (int e = 0; e < 4; e++) packed = __builtin_amdgcn_cvt_pk_u8_f32(accs[e], e, packed);
+                            if (EXACT) {  // the H pass's test: fract(|acc|) - 0.5 in [0, 2 eps) = undecided
+                                uint32_t gmin = 0x7f800000u;
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const uint32_t gu = __builtin_bit_cast(uint32_t, __builtin_amdgcn_fractf(__builtin_fabsf(accs[e])) - 0.5f);
+                                    gmin = gu < gmin ? gu : gmin;
+                                }
+                                undecided = gmin < __builtin_bit_cast(uint32_t, near2);
+                            }
                         } else if (SB == 2 && !EXACT && K::PK16) {
                             // floor(sum + eps) clamped to [0, 65535]: max with 0, truncating convert, saturating pack
                             const unsigned u0 = (unsigned)__builtin_fmaxf(accs[0], 0.0f), u1 = (unsigned)__builtin_fmaxf(accs[1], 0.0f);
