@@ -374,6 +374,25 @@ def test_full_size_config5_digest(ctx):
         assert f"{O.fnv1a64(got):016x}" == kat[shape], shape
 
 
+def test_full_size_config5_batch_every_frame(ctx):
+    """Config 5 as a batch of 4 identical frames (PARITY UNPINNED BY THE REFERENCE, as above): this launch shape takes the
+    marching kernel's table mode A -- one workgroup per CU slot, shares that run from one (strip, frame) pair into the next
+    (lanczos_march.hpp: march_build_table).  Every frame must equal frame 0 and frame 0 the committed digest."""
+    with open(os.path.join(GOLD, "kat_digests_u16.json")) as f:
+        kat = json.load(f)["digests"]
+    w, h, c, sn, sd, a = C5
+    frame = _c5_frame()
+    batch = np.ascontiguousarray(np.broadcast_to(frame, (4,) + frame.shape))
+    got = ctx.resample(batch, sn, sd, a, L.MODE_EXACT)
+    assert f"{O.fnv1a64(got[0]):016x}" == kat["3840x2160_7680x4320_2-1_a4_c4"]
+    for i in range(1, 4):
+        assert np.array_equal(got[i], got[0]), f"EXACT: frame {i} differs from frame 0"
+    fast = ctx.resample(batch, sn, sd, a, L.MODE_LSB1)
+    assert np.abs(fast[0].astype(np.int32) - got[0].astype(np.int32)).max() <= 1
+    for i in range(1, 4):
+        assert np.array_equal(fast[i], fast[0]), f"LSB1: frame {i} differs from frame 0"
+
+
 def test_full_size_config5_against_oracle(ctx):
     """Both parity modes at full size, every sample against the threaded checker; gradient-like u16 content
     (the LCG noise frame is covered by the digest test)."""
