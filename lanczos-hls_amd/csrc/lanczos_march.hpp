@@ -86,6 +86,7 @@ struct MarchShape {
     static constexpr int NGRP = 2;                                  // V groups (whole waves each)
     static constexpr int MS = 2 * A * NGRP;                         // input rows per tick
     static constexpr bool SPLIT = false;
+    static constexpr bool CARRY = false;                            // V window carried from tick to tick (one group, MS % 2a == 0)
     static constexpr int P = 0, UPR = 0;                            // unit geometry: FastCfg's default
 };
 template <int A>
@@ -97,14 +98,29 @@ struct MarchShape<uint8_t, 3, 3, A> {  // 288 dword columns = 4.5 waves per V gr
 #endif
     static constexpr int MS = 12;
     static constexpr bool SPLIT = false;
+    static constexpr bool CARRY = false;
     static constexpr int P = 0, UPR = 0;
 };
-#ifdef LZ_MARCH_SPLIT  // opt-in experiment (round 2): no faster than the 6-wave all-roles workgroup, slower on fix-up-heavy input
+#ifdef LZ_MARCH_FINE
+// opt-in experiment: 3-wave workgroups, 6-row ticks, every thread owns one H unit per tick AND one dword column whose 2a-row
+// window it carries from tick to tick (no re-seeding: 20 of 44 conversions per 6 rows saved), half the prologue per chunk.
+// Measured (profiles/round2h_ab_fine_grained_workgroups.txt): 82 VGPRs, six workgroups = 18 waves per CU, 224 us against 209
+// on config 2 at 32 frames (outputs identical): fewer waves and twice the barriers cost more than the conversions save.
+template <>
+struct MarchShape<uint8_t, 3, 2, 3> {
+    static constexpr int NGRP = 1;
+    static constexpr int MS = 6;
+    static constexpr bool SPLIT = false;
+    static constexpr bool CARRY = true;
+    static constexpr int P = 0, UPR = 0;
+};
+#elif defined(LZ_MARCH_SPLIT)  // opt-in experiment (round 2): no faster than the 6-wave all-roles workgroup, slower on fix-up-heavy input
 template <>
 struct MarchShape<uint8_t, 3, 2, 3> {  // config 2: 3 H waves (12 rows x 16 units) + 3 V waves (192 dword columns x 12 rows)
     static constexpr int NGRP = 1;
     static constexpr int MS = 12;
     static constexpr bool SPLIT = true;
+    static constexpr bool CARRY = true;
     static constexpr int P = 8, UPR = 16;
 };
 #elif defined(LZ_MARCH_WG8)
@@ -116,6 +132,7 @@ struct MarchShape<uint8_t, 3, 2, 3> {
     static constexpr int NGRP = 2;
     static constexpr int MS = 12;
     static constexpr bool SPLIT = false;
+    static constexpr bool CARRY = false;
     static constexpr int P = 4, UPR = 40;
 };
 #endif
@@ -126,6 +143,7 @@ struct MarchCfg {
     using F = FastCfg<T, C_, S_, A_, SH::P, SH::UPR>;  // unit geometry (the default one is shared with the tile kernel)
     static constexpr int C = C_, S = S_, A = A_;
     static constexpr bool SPLIT = SH::SPLIT;
+    static constexpr bool CARRY = SH::CARRY;
     static constexpr int SB = F::SB, TAPS = F::TAPS, P = F::P, UPR = F::UPR;
     static constexpr int NGRP = SH::NGRP;
     static constexpr int MS = SH::MS;
@@ -142,7 +160,7 @@ struct MarchCfg {
 #ifdef LZ_MARCH_RING_POW2
     static constexpr int RS = (2 * MS + TAPS - 1) <= 32 ? 32 : 64;
 #else
-    static constexpr int RS = (2 * MS + TAPS - 1) <= 32 ? 32 : ((2 * MS + TAPS - 1 + 7) / 8) * 8;
+    static constexpr int RS = (CARRY && !SPLIT && (2 * MS + TAPS - 1) <= 24) ? 24 : ((2 * MS + TAPS - 1) <= 32 ? 32 : ((2 * MS + TAPS - 1 + 7) / 8) * 8);
 #endif
     static constexpr bool RS_POW2 = (RS & (RS - 1)) == 0;
     // slot of ring row `rel` = row - hb (>= -RS: the first ticks read rows above the chunk, whose results are never stored)
@@ -257,7 +275,7 @@ struct MarchCfg {
     static constexpr int WL_SMP_BITS = F::UNIT_OUT_S <= 32 ? 5 : 6;
     static constexpr int WL_UNIT_BITS = UPR <= 16 ? 4 : (UPR <= 32 ? 5 : 6);
     static_assert(F::UNIT_OUT_S <= 64 && UPR <= 64 && MS <= (1 << (16 - WL_SMP_BITS - WL_UNIT_BITS)), "worklist entry fits 16 bits");
-    static_assert(!SPLIT || (NGRP == 1 && MS % TAPS == 0), "carried V window: one group, the slot rotation realigns every tick");
+    static_assert(!CARRY || (NGRP == 1 && MS % TAPS == 0), "carried V window: one group, the slot rotation realigns every tick");
 };
 
 // RIDE: the launch also carries the in-place prefix rows as extra workgroups behind the marching ones (small batches:
@@ -803,7 +821,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     // SPLIT: the V window lives across ticks (the slot rotation realigns every MS = k * TAPS rows)
     float win[TAPS][F::VEC];
     uint32_t raw[TAPS];
-    if (K::SPLIT) {
+    if (K::CARRY) {
 #pragma unroll
         for (int k = 0; k < TAPS; k++) {
             raw[k] = 0;
@@ -837,7 +855,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         auto ring = [&](int r) { return hcol[K::ring_slot(r - hb) * HP]; };  // H row r of this column
         // rows m_g-a+1 .. m_g+a-1 seed the window; rows before hb were never produced: only read for m < m_b,
         // whose outputs are not stored
-        if (!K::SPLIT) {
+        if (!K::CARRY) {
 #pragma unroll
             for (int k = 0; k < TAPS - 1; k++) unpack(k, ring(m_g - A + 1 + k));
         }
