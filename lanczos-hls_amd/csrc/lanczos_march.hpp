@@ -221,6 +221,15 @@ struct MarchCfg {
 #else
     static constexpr bool EARLY = SB == 2;
 #endif
+    // wave priority in the H pass / the V pass (0 elsewhere).  Round 1: (3, 2) beats equal priorities by 11-13 % (the H pass
+    // feeds the ring every other wave's next V pass waits for).  Again with inputs from HBM (profiles/round2h_ab_wave_priority
+    // .txt): config 2 (3,2) 210.5 / (3,1) 210.6 / (2,3) 212.2 / (3,3) 216.2 / (0,0) 217.4 us; config 3, whose V pass is
+    // two thirds of the work, (2,3) 209.2 against (3,2) 213.8
+#if defined(LZ_MARCH_PRIO_H) && defined(LZ_MARCH_PRIO_V)
+    static constexpr int PRIO_H = LZ_MARCH_PRIO_H, PRIO_V = LZ_MARCH_PRIO_V;
+#else
+    static constexpr int PRIO_H = S == 3 ? 2 : 3, PRIO_V = S == 3 ? 3 : 2;
+#endif
 #ifdef LZ_MARCH_NO_MIRROR
     static constexpr bool MIRROR = false;
 #else
@@ -1086,7 +1095,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         const unsigned long long t1 = stamp();
         // Wave priority by phase (measured, interleaved on one device: H=3/V=2/else=0 is 11-13 % faster than all
         // equal): the H pass feeds the ring every other wave's next V pass waits for, so it goes first.
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(K::PRIO_H);
         if (tick + 1 < ticks) hpass(tick + 1);
         __builtin_amdgcn_s_setprio(0);
         const unsigned long long t2 = stamp();
@@ -1098,7 +1107,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         else commit_loads(tick & 1);
         if (!K::LDSDMA && K::EARLY) issue_loads(tick + 3);  // committed after the NEXT tick's H pass (see MarchCfg::EARLY)
         const unsigned long long t3 = stamp();
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(K::PRIO_V);
         const bool full = vpass(tick);
         __builtin_amdgcn_s_setprio(0);
         if (K::LDSDMA) {
