@@ -5,32 +5,39 @@
 // cyclic_buffer.h:4-69): a ring of horizontally-resampled rows lives in LDS and is advanced MS input rows
 // per "tick"; nothing but the input and output frames ever touches HBM.
 //
-// Workgroup = one strip of TWP_OUT output pixels x one vertical chunk of the frame.  ONE barrier per tick;
-// between two barriers every wave runs, back to back and independent of the other waves:
+// Workgroup = one strip of TWP_OUT output pixels x a share of rows that the host hands it through a table indexed by
+// the hardware block id (march_build_table): one to three segments, each a run of rows of one (strip, frame) pair.  Inside a
+// segment ONE barrier per tick; between two barriers every wave runs, back to back and independent of the other waves:
 //   PREFETCH  one 16-byte buffer load per lane of the input rows two ticks ahead (out-of-image lanes read
 //             zeros through the descriptor's range check: a dropped tap is a zero contribution)
 //   HPASS     tick t+1: one unit (P input pixels -> P*S output pixels of one row) per thread from the LDS
-//             input rows: aligned dword reads, v_cvt_f32_ubyteN, 2a-tap fmaf chains with SGPR weights,
+//             input rows: aligned dword reads, v_cvt_f32_ubyteN, pair sums + fmaf chains with VGPR weights,
 //             v_perm_b32 / v_cvt_pk_u8_f32 packing, truncated integers into the LDS ring (the reference's
 //             between-pass store, full_TB.h:63)
-//   FIXUP     samples the f32 chain cannot decide are compacted per WAVE (ballot + mbcnt, no atomics) into a
-//             wave-private LDS list and redone densely with the exact f64 chain (full_TB.h:58-63):
+//   FIXUP     samples the f32 chain cannot decide are put on a wave-private LDS list (integer-phase candidates: ballot +
+//             mbcnt compaction; near-integer units: written by the first lanes directly) and redone densely with the exact
+//             f64 chain (full_TB.h:58-63), whose phase weights live in LDS:
 //               - a sum within +-eps of an integer (eps = proven f32 error bound)
 //               - an integer-phase sample whose double sum v0 + O(1e-17) may truncate to v0-1:
 //                 1 <= v0 <= vlim and a +-2 neighbour brighter than 2*v0 (SWAR tests on the packed bytes)
 //   VPASS     tick t: one dword column per thread, 2a-row register window over the ring; integer-phase rows
-//             are dword copies, the others 2a fmaf + one v_cvt_pk_u8_f32 per sample; buffer stores with the
+//             are dword copies, the others pair sums + fmaf + one v_cvt_pk_u8_f32 per sample; buffer stores with the
 //             row offset in the scalar operand
-// ~40 KiB of LDS per workgroup: 4 workgroups (24 waves) per CU at 72 VGPRs / 96 SGPRs.
+// Config 2: 40.6 KB of LDS per workgroup, 68 VGPRs / 96 SGPRs: 4 workgroups (24 waves) per CU.
+//
+// What bounds it: the memory system.  The kernel's traffic alone -- the same store and load segments, nothing
+// else -- takes 176 us per 32 frames of config 2 (0.707 of 8 TB/s; reads and writes do not overlap in the DRAM); the kernel
+// takes 203-212 us, of which its arithmetic adds 15-25 us on top of its own memory skeleton.
 //
 // Around the tick loop (all measured, profiles/README.md):
-//   * the grid is 1-D and re-numbered so that the ids one XCD receives are consecutive: neighbouring strips share an L2
-//     and every input line is fetched from HBM once;
+//   * the table deals whole frames to every XCD (neighbouring strips share an L2: every input line is fetched from HBM once)
+//     and gives the workgroup slots a CU fills first -- whose waves are older and win the SIMD arbitration -- more rows;
 //   * the output stores are non-temporal (the output must not evict the input rows neighbours re-read);
-//   * the phase weights live in VGPRs (an SGPR source puts a VALU op in gfx950's slow issue class), the exact chain's
-//     double weights in memory (as kernel arguments they cost 24 SGPRs and spilled);
+//   * the phase weights live in VGPRs (an SGPR source puts a VALU op in gfx950's slow issue class);
+//   * per-lane indices are rebuilt every tick from an opaque copy of the thread id (held across the segment loop they cost a
+//     fourth workgroup per CU);
 //   * RIDE variant (small batches): the in-place prefix rows (k_prefix) are extra workgroups at the end of this grid;
-//   * EXACT variant: the V pass keeps its exactness test; undecided rows are redone in f64 after the row loop.
+//   * EXACT variant: the V pass keeps the H pass's exactness tests; undecided rows are redone in f64 after the row loop.
 #pragma once
 #include <cstdio>
 #include <cstdlib>
