@@ -46,6 +46,7 @@ extern "C" {
 #define LANCZOS_ERR_NO_DEVICE 3    /* no HIP device / device index out of range */
 #define LANCZOS_ERR_HIP 4          /* a HIP runtime call failed; see lanczos_last_hip_error() */
 #define LANCZOS_ERR_NOMEM 5
+#define LANCZOS_ERR_RCCL 6         /* an RCCL call of the root exchange failed; see lanczos_multi_last_error() */
 
 /* parity modes (lanczos_desc.mode) */
 #define LANCZOS_MODE_LSB1 0   /* default: horizontal pass bit-exact, vertical pass f32 accumulators;
@@ -156,9 +157,29 @@ int lanczos_multi_devices(const lanczos_multi* m);
  * its own PCIe link.  Results are those of lanczos_resample_host on one device. */
 int lanczos_resample_multi_host(lanczos_multi* m, const lanczos_desc* d, const void* in, void* out, int frames, int split);
 /* Frames resident on the ROOT device (devices[0]): scatter (RCCL ncclSend/ncclRecv group over xGMI) -> resample on every
- * device -> gather.  Synchronous.  compute_ms / total_ms may be NULL.  librccl is loaded on first use (n_devices > 1). */
+ * device -> gather.  Synchronous.  compute_ms / total_ms may be NULL.  librccl is loaded on first use (n_devices > 1).
+ * EXPERIMENTAL with more than one device: the exchange has not run on multi-GPU hardware yet (no such node was
+ * available to the builders).  What is checked without it: the message lists (lanczos_multi_exchange_plan, below) against the
+ * partition functions, and the group handling -- every ncclSend / ncclRecv code looked at, an opened group always closed, the
+ * first failure reported as LANCZOS_ERR_RCCL with lanczos_multi_last_error().  The caller's current HIP device is preserved. */
 int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const void* d_in_root, void* d_out_root, int frames,
                                 int split, double* compute_ms, double* total_ms);
+/* What the last lanczos_resample_multi_root call saw: the HIP error, the ncclResult_t of the first failing RCCL call and which
+ * message of the list it was (-1: ncclGroupStart / ncclCommInitAll, list size: ncclGroupEnd).  Pointers may be NULL. */
+int lanczos_multi_last_error(const lanczos_multi* m, int* hip_error, int* rccl_error, int* rccl_message);
+/* The root exchange as data (host only, no GPU): message k moves `bytes` from rank `src`'s buffer at src_off to rank `dst`'s
+ * buffer at dst_off.  Rank 0's buffers are the caller's root buffers (all frames), a peer's buffer is its shard (split by
+ * frames: its frames back to back; split by rows: its strip of every frame, frame after frame).  phase 0 = scatter of the inputs,
+ * 1 = gather of the outputs.  Returns the number of messages (call with cap = 0 to size `out`), or -LANCZOS_ERR_*. */
+typedef struct lanczos_xfer {
+    int src, dst;
+    size_t src_off, dst_off, bytes;
+} lanczos_xfer;
+int lanczos_multi_exchange_plan(const lanczos_desc* d, int frames, int split, int n_devices, int phase, lanczos_xfer* out, int cap);
+/* Device memory for plain-C callers that do not include the HIP headers (host/main.c --root). */
+int lanczos_device_alloc(int device, void** p, size_t bytes);
+int lanczos_device_free(int device, void* p);
+int lanczos_device_copy(int device, void* dst, const void* src, size_t bytes, int to_device);
 
 /* ---- measurement / introspection ---- */
 /* When enabled, every lanczos_resample_device call brackets its main kernel with HIP events on the

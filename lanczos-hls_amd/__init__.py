@@ -36,6 +36,8 @@ ABI_SYMBOLS = [
     "lanczos_version",
     "lanczos_partition_frames", "lanczos_partition_rows", "lanczos_multi_create", "lanczos_multi_destroy",
     "lanczos_multi_devices", "lanczos_resample_multi_host", "lanczos_resample_multi_root",
+    "lanczos_multi_last_error", "lanczos_multi_exchange_plan", "lanczos_device_alloc", "lanczos_device_free",
+    "lanczos_device_copy",
 ]
 SPLIT_FRAMES, SPLIT_ROWS = 0, 1
 
@@ -312,6 +314,27 @@ def partition_rows(desc, parts, part):
     v = [ctypes.c_int() for _ in range(4)]
     _check(_lib().lanczos_partition_rows(ctypes.byref(desc), parts, part, *[ctypes.byref(x) for x in v]), "lanczos_partition_rows")
     return tuple(x.value for x in v)   # out_row0, out_rows, in_row0, in_rows
+
+
+class Xfer(ctypes.Structure):
+    """lanczos_xfer -- one message of the root exchange (lanczos_multi_exchange_plan)."""
+    _fields_ = [("src", ctypes.c_int), ("dst", ctypes.c_int), ("src_off", ctypes.c_size_t), ("dst_off", ctypes.c_size_t),
+                ("bytes", ctypes.c_size_t)]
+
+
+def exchange_plan(desc, frames, split, n_devices, phase):
+    """The scatter (phase 0) / gather (phase 1) of lanczos_resample_multi_root as a list of (src, dst, src_off, dst_off, bytes).
+    Host only: no GPU, no RCCL."""
+    fn = _lib().lanczos_multi_exchange_plan
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.POINTER(Desc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(Xfer), ctypes.c_int]
+    n = fn(ctypes.byref(desc), frames, split, n_devices, phase, None, 0)
+    if n < 0:
+        raise LanczosError(-n, "lanczos_multi_exchange_plan")
+    arr = (Xfer * max(n, 1))()
+    n2 = fn(ctypes.byref(desc), frames, split, n_devices, phase, arr, n)
+    assert n2 == n
+    return [(x.src, x.dst, x.src_off, x.dst_off, x.bytes) for x in arr[:n]]
 
 
 class MultiContext:

@@ -232,6 +232,7 @@ const char* lanczos_strerror(int code) {
         case LANCZOS_ERR_NO_DEVICE: return "no HIP device";
         case LANCZOS_ERR_HIP: return "HIP runtime error";
         case LANCZOS_ERR_NOMEM: return "out of memory";
+        case LANCZOS_ERR_RCCL: return "RCCL call failed (lanczos_multi_last_error)";
         default: return "unknown error";
     }
 }
@@ -412,6 +413,17 @@ int lanczos_destroy(lanczos_ctx* ctx) {
             if (n)
                 fprintf(stderr, "STAMP waves=%ld ticks/wave=%.1f cycles/tick: issue=%.0f hpass=%.0f commit=%.0f vpass=%.0f barrier=%.0f\n",
                         n, ticks / n, sum[0] / ticks, sum[1] / ticks, sum[2] / ticks, sum[3] / ticks, sum[4] / ticks);
+            for (int w = 0; w < 6; w++) {  // the same by wave index inside the workgroup (k_march<u8,3,2,3>: 6 waves; 0-2 run the H pass)
+                double s6[5] = {0, 0, 0, 0, 0}, tk = 0;
+                for (size_t i = (size_t)w * 6; i + 5 < (size_t)16384 * 8 * 3; i += 36)
+                    if (h[i + 5]) {
+                        for (int k = 0; k < 5; k++) s6[k] += (double)h[i + k];
+                        tk += (double)h[i + 5];
+                    }
+                if (tk > 0)
+                    fprintf(stderr, "STAMP wave %d: issue=%.0f hpass=%.0f commit=%.0f vpass=%.0f barrier=%.0f\n", w, s6[0] / tk, s6[1] / tk,
+                            s6[2] / tk, s6[3] / tk, s6[4] / tk);
+            }
         }
         (void)hipFree(ctx->stamp_buf);
     }

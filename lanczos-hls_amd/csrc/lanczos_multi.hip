@@ -21,8 +21,20 @@
 #include <vector>
 
 #include "../../include/lanczos_hip.h"
+#include "lanczos_exchange.hpp"
 
 namespace {
+
+// every entry below walks over the devices with hipSetDevice: the caller's current device is put back on every return path
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    }
+    ~DeviceGuard() {
+        if (dev >= 0) (void)hipSetDevice(dev);
+    }
+};
 
 // ---- the slice of rccl.h this file uses (declared here so that the library has no link-time dependency on librccl)
 typedef struct ncclComm* ncclComm_t;
@@ -65,7 +77,39 @@ struct lanczos_multi {
     std::vector<void*> d_in, d_out;         // per-device shard buffers (device 0 works in place on the root buffers)
     std::vector<size_t> d_in_bytes, d_out_bytes;
     int last_hip = 0;
+    int last_rccl = 0;       // first ncclResult_t a group reported (0 = none)
+    int last_rccl_at = 0;    // which message of the list (-1: ncclGroupStart, list size: ncclGroupEnd)
 };
+
+namespace {
+
+// shares of a call: the partition functions of the C ABI, applied to every rank
+int make_shares(const lanczos_desc* d, int frames, int split, int n, std::vector<lz::ExShare>* sh, lz::ExGeometry* g) {
+    g->in_frame = lanczos_in_frame_bytes(d);
+    g->out_frame = lanczos_out_frame_bytes(d);
+    g->in_pitch = (size_t)d->in_w * d->channels * d->bytes_per_sample;
+    g->out_pitch = (size_t)d->out_w * d->channels * d->bytes_per_sample;
+    g->frames = frames;
+    g->by_rows = split == LANCZOS_SPLIT_ROWS;
+    sh->assign(n, lz::ExShare());
+    for (int i = 0; i < n; i++) {
+        lz::ExShare& s = (*sh)[i];
+        s.f0 = 0, s.cnt = frames, s.r0 = 0, s.rows = d->out_h, s.i0 = 0, s.irows = d->in_h;
+        if (!g->by_rows) {
+            lanczos_partition_frames(frames, n, i, &s.f0, &s.cnt);
+            s.in_bytes = (size_t)s.cnt * g->in_frame;
+            s.out_bytes = (size_t)s.cnt * g->out_frame;
+        } else {
+            const int rc = lanczos_partition_rows(d, n, i, &s.r0, &s.rows, &s.i0, &s.irows);
+            if (rc != LANCZOS_OK) return rc;
+            s.in_bytes = (size_t)frames * s.irows * g->in_pitch;    // strip-major shard: [frame][strip rows]
+            s.out_bytes = (size_t)frames * s.rows * g->out_pitch;
+        }
+    }
+    return LANCZOS_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -103,6 +147,7 @@ int lanczos_partition_rows(const lanczos_desc* d, int parts, int part, int* out_
 int lanczos_multi_create(lanczos_multi** out, const int* devices, int n_devices) {
     if (!out || !devices || n_devices < 1 || n_devices > 64) return LANCZOS_ERR_BAD_ARG;
     *out = nullptr;
+    DeviceGuard restore;  // lanczos_create selects each device in turn
     lanczos_multi* m = new (std::nothrow) lanczos_multi();
     if (!m) return LANCZOS_ERR_NOMEM;
     for (int i = 0; i < n_devices; i++) {
@@ -122,6 +167,7 @@ int lanczos_multi_create(lanczos_multi** out, const int* devices, int n_devices)
 
 int lanczos_multi_destroy(lanczos_multi* m) {
     if (!m) return LANCZOS_ERR_BAD_ARG;
+    DeviceGuard restore;
     for (size_t i = 0; i < m->streams.size(); i++) {
         (void)hipSetDevice(m->devices[i]);
         if (m->streams[i]) (void)hipStreamSynchronize(m->streams[i]);
@@ -140,6 +186,35 @@ int lanczos_multi_destroy(lanczos_multi* m) {
 }
 
 int lanczos_multi_devices(const lanczos_multi* m) { return m ? (int)m->ctx.size() : 0; }
+
+int lanczos_multi_last_error(const lanczos_multi* m, int* hip_error, int* rccl_error, int* rccl_message) {
+    if (!m) return LANCZOS_ERR_BAD_ARG;
+    if (hip_error) *hip_error = m->last_hip;
+    if (rccl_error) *rccl_error = m->last_rccl;
+    if (rccl_message) *rccl_message = m->last_rccl_at;
+    return LANCZOS_OK;
+}
+
+// The exchange of lanczos_resample_multi_root as data (no device needed): phase 0 = scatter (root -> peers, input shares),
+// phase 1 = gather (peers -> root, output shares).  Returns the number of messages (also when `cap` is smaller: call with
+// cap = 0 to size the array), or a negative LANCZOS_ERR_*.
+int lanczos_multi_exchange_plan(const lanczos_desc* d, int frames, int split, int n_devices, int phase, lanczos_xfer* out, int cap) {
+    int rc = lanczos_validate(d);
+    if (rc != LANCZOS_OK) return -rc;
+    if (frames <= 0 || n_devices < 1 || n_devices > 64 || (phase != 0 && phase != 1) || cap < 0 || (cap > 0 && !out)) return -LANCZOS_ERR_BAD_ARG;
+    if (split != LANCZOS_SPLIT_FRAMES && split != LANCZOS_SPLIT_ROWS) return -LANCZOS_ERR_BAD_ARG;
+    if (d->out_rows != 0 && !(d->out_row0 == 0 && d->out_rows == d->out_h)) return -LANCZOS_ERR_BAD_ARG;
+    std::vector<lz::ExShare> sh;
+    lz::ExGeometry g;
+    rc = make_shares(d, frames, split, n_devices, &sh, &g);
+    if (rc != LANCZOS_OK) return -rc;
+    std::vector<lz::ExXfer> list;
+    if (phase == 0) lz::exchange_scatter_plan(g, sh, &list);
+    else lz::exchange_gather_plan(g, sh, &list);
+    for (int k = 0; k < (int)list.size() && k < cap; k++)
+        out[k] = lanczos_xfer{list[k].src, list[k].dst, list[k].src_off, list[k].dst_off, list[k].bytes};
+    return (int)list.size();
+}
 
 // Host buffers in, host buffers out: `frames` whole frames back to back (what lanczos_resample_host takes).  One thread per
 // device; every device moves only its own share over its own PCIe link.
@@ -195,6 +270,10 @@ int lanczos_resample_multi_host(lanczos_multi* m, const lanczos_desc* d, const v
 // Frames resident on the ROOT device (devices[0]) in, results on the root device out.  scatter (ncclSend/ncclRecv group) ->
 // every device resamples its share -> gather (second group).  Synchronous.  compute_ms / total_ms (optional): wall time of
 // the resample step alone (max over devices) and of the whole call.
+//
+// STATUS: with more than one device this entry has NOT run on hardware (no multi-GPU node was available to the builders); the
+// message lists and the group handling are checked on the CPU (tests/test_multi_entry.py: lanczos_multi_exchange_plan against
+// lanczos_partition_*; tests/native/exchange_check.cpp: every send/recv code looked at, the group closed on every path).
 int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const void* d_in_root, void* d_out_root, int frames,
                                 int split, double* compute_ms, double* total_ms) {
     if (!m || !d_in_root || !d_out_root || frames <= 0) return LANCZOS_ERR_BAD_ARG;
@@ -206,6 +285,8 @@ int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const v
     for (int i = 0; i < n; i++)
         for (int j = 0; j < i; j++)
             if (m->devices[i] == m->devices[j]) return LANCZOS_ERR_BAD_ARG;  // one rank per physical device
+    DeviceGuard restore;  // the caller's current device (its inputs live on devices[0]) is put back on every return path
+    m->last_hip = m->last_rccl = m->last_rccl_at = 0;
     if (m->streams.empty()) {
         m->streams.assign(n, nullptr);
         m->d_in.assign(n, nullptr);
@@ -220,31 +301,19 @@ int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const v
     if (n > 1 && m->comms.empty()) {
         if (!m->rccl.load()) return LANCZOS_ERR_UNSUPPORTED;  // no librccl on this system
         m->comms.assign(n, nullptr);
-        if (m->rccl.CommInitAll(m->comms.data(), n, m->devices.data()) != 0) {
+        const int r = m->rccl.CommInitAll(m->comms.data(), n, m->devices.data());
+        if (r != 0) {
             m->comms.clear();
-            return LANCZOS_ERR_HIP;
+            m->last_rccl = r;
+            m->last_rccl_at = -1;
+            return LANCZOS_ERR_RCCL;
         }
     }
-    const size_t in_frame = lanczos_in_frame_bytes(d), out_frame = lanczos_out_frame_bytes(d);
-    const size_t in_pitch = (size_t)d->in_w * d->channels * d->bytes_per_sample;
-    const size_t out_pitch = (size_t)d->out_w * d->channels * d->bytes_per_sample;
-    // shares: frames -> (first frame, count); rows -> (out_row0, out_rows, in_row0, in_rows), the same strip of every frame
-    struct Share { int f0, cnt, r0, rows, i0, irows; size_t in_bytes, out_bytes; };
-    std::vector<Share> sh(n);
-    for (int i = 0; i < n; i++) {
-        Share& s = sh[i];
-        s = Share{0, frames, 0, d->out_h, 0, d->in_h, 0, 0};
-        if (split == LANCZOS_SPLIT_FRAMES) {
-            lanczos_partition_frames(frames, n, i, &s.f0, &s.cnt);
-            s.in_bytes = (size_t)s.cnt * in_frame;
-            s.out_bytes = (size_t)s.cnt * out_frame;
-        } else {
-            rc = lanczos_partition_rows(d, n, i, &s.r0, &s.rows, &s.i0, &s.irows);
-            if (rc != LANCZOS_OK) return rc;
-            s.in_bytes = (size_t)frames * s.irows * in_pitch;    // strip-major shard: [frame][strip rows]
-            s.out_bytes = (size_t)frames * s.rows * out_pitch;
-        }
-    }
+    std::vector<lz::ExShare> sh;
+    lz::ExGeometry geo;
+    rc = make_shares(d, frames, split, n, &sh, &geo);
+    if (rc != LANCZOS_OK) return rc;
+    const size_t in_frame = geo.in_frame, out_frame = geo.out_frame, in_pitch = geo.in_pitch, out_pitch = geo.out_pitch;
     for (int i = 1; i < n; i++) {  // peer shard buffers
         LZM_HIP(hipSetDevice(m->devices[i]));
         if (m->d_in_bytes[i] < sh[i].in_bytes) {
@@ -274,30 +343,45 @@ int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const v
         }
         return LANCZOS_OK;
     };
-    const double t_start = now_ms();
-    // ---- scatter: root sends every peer its input share (one send per contiguous piece), peers receive
-    if (n > 1) {
-        if (m->rccl.GroupStart() != 0) return LANCZOS_ERR_HIP;
-        for (int i = 1; i < n; i++) {
-            if (sh[i].in_bytes == 0) continue;
-            if (split == LANCZOS_SPLIT_FRAMES) {
-                m->rccl.Send((const uint8_t*)d_in_root + (size_t)sh[i].f0 * in_frame, sh[i].in_bytes, kNcclUint8, i, m->comms[0], m->streams[0]);
-                m->rccl.Recv(m->d_in[i], sh[i].in_bytes, kNcclUint8, 0, m->comms[i], m->streams[i]);
-            } else {
-                const size_t piece = (size_t)sh[i].irows * in_pitch;
-                for (int f = 0; f < frames; f++) {
-                    m->rccl.Send((const uint8_t*)d_in_root + (size_t)f * in_frame + (size_t)sh[i].i0 * in_pitch, piece, kNcclUint8, i, m->comms[0], m->streams[0]);
-                    m->rccl.Recv((uint8_t*)m->d_in[i] + (size_t)f * piece, piece, kNcclUint8, 0, m->comms[i], m->streams[i]);
-                }
-            }
+    // one list = one RCCL group; rank r's buffer: the root's caller buffers (r == 0) or the peer's shard buffer
+    struct Ops {
+        lanczos_multi* m;
+        const uint8_t* root_src;   // what rank 0 sends from
+        uint8_t* root_dst;         // what rank 0 receives into
+        bool scatter;
+        int group_start() { return m->rccl.GroupStart(); }
+        int group_end() { return m->rccl.GroupEnd(); }
+        int send(int rank, size_t off, size_t bytes, int peer) {
+            const uint8_t* base = rank == 0 ? root_src : (const uint8_t*)(scatter ? m->d_in[rank] : m->d_out[rank]);
+            return m->rccl.Send(base + off, bytes, kNcclUint8, peer, m->comms[rank], m->streams[rank]);
         }
-        if (m->rccl.GroupEnd() != 0) return LANCZOS_ERR_HIP;
-    }
+        int recv(int rank, size_t off, size_t bytes, int peer) {
+            uint8_t* base = rank == 0 ? root_dst : (uint8_t*)(scatter ? m->d_in[rank] : m->d_out[rank]);
+            return m->rccl.Recv(base + off, bytes, kNcclUint8, peer, m->comms[rank], m->streams[rank]);
+        }
+    };
+    auto exchange = [&](bool scatter) -> int {
+        std::vector<lz::ExXfer> list;
+        if (scatter) lz::exchange_scatter_plan(geo, sh, &list);
+        else lz::exchange_gather_plan(geo, sh, &list);
+        Ops ops{m, (const uint8_t*)d_in_root, (uint8_t*)d_out_root, scatter};
+        int at = 0;
+        const int r = lz::exchange_run(ops, list, &at);
+        if (r != 0) {
+            m->last_rccl = r;
+            m->last_rccl_at = at;
+            (void)sync_all();  // whatever was queued before the failure is drained before the caller sees the error
+            return LANCZOS_ERR_RCCL;
+        }
+        return LANCZOS_OK;
+    };
+    const double t_start = now_ms();
+    if (n > 1 && (rc = exchange(true)) != LANCZOS_OK) return rc;   // ---- scatter: root -> peers
     if ((rc = sync_all()) != LANCZOS_OK) return rc;
     const double t_c0 = now_ms();
     // ---- compute: every device its share, on its own stream
     for (int i = 0; i < n; i++) {
-        const Share& s = sh[i];
+        const lz::ExShare& s = sh[i];
         if (s.out_bytes == 0) continue;
         lanczos_desc dd = *d;
         dd.out_row0 = dd.out_rows = 0;
@@ -314,32 +398,41 @@ int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const v
             else
                 rc = lanczos_resample_device(m->ctx[i], &dd, m->d_in[i], m->d_out[i], frames, 0, 0, m->streams[i]);
         }
-        if (rc != LANCZOS_OK) return rc;
+        if (rc != LANCZOS_OK) {
+            (void)sync_all();
+            return rc;
+        }
     }
     if ((rc = sync_all()) != LANCZOS_OK) return rc;
     const double t_c1 = now_ms();
-    // ---- gather
-    if (n > 1) {
-        if (m->rccl.GroupStart() != 0) return LANCZOS_ERR_HIP;
-        for (int i = 1; i < n; i++) {
-            if (sh[i].out_bytes == 0) continue;
-            if (split == LANCZOS_SPLIT_FRAMES) {
-                m->rccl.Send(m->d_out[i], sh[i].out_bytes, kNcclUint8, 0, m->comms[i], m->streams[i]);
-                m->rccl.Recv((uint8_t*)d_out_root + (size_t)sh[i].f0 * out_frame, sh[i].out_bytes, kNcclUint8, i, m->comms[0], m->streams[0]);
-            } else {
-                const size_t piece = (size_t)sh[i].rows * out_pitch;
-                for (int f = 0; f < frames; f++) {
-                    m->rccl.Send((const uint8_t*)m->d_out[i] + (size_t)f * piece, piece, kNcclUint8, 0, m->comms[i], m->streams[i]);
-                    m->rccl.Recv((uint8_t*)d_out_root + (size_t)f * out_frame + (size_t)sh[i].r0 * out_pitch, piece, kNcclUint8, i, m->comms[0], m->streams[0]);
-                }
-            }
-        }
-        if (m->rccl.GroupEnd() != 0) return LANCZOS_ERR_HIP;
-    }
+    if (n > 1 && (rc = exchange(false)) != LANCZOS_OK) return rc;  // ---- gather: peers -> root
     if ((rc = sync_all()) != LANCZOS_OK) return rc;
     if (compute_ms) *compute_ms = t_c1 - t_c0;
     if (total_ms) *total_ms = now_ms() - t_start;
     return LANCZOS_OK;
+}
+
+// ---- plain-C callers without the HIP headers (host/main.c --root): device memory on a chosen device
+int lanczos_device_alloc(int device, void** p, size_t bytes) {
+    if (!p || bytes == 0) return LANCZOS_ERR_BAD_ARG;
+    *p = nullptr;
+    DeviceGuard restore;
+    if (hipSetDevice(device) != hipSuccess) return LANCZOS_ERR_NO_DEVICE;
+    return hipMalloc(p, bytes) == hipSuccess ? LANCZOS_OK : LANCZOS_ERR_NOMEM;
+}
+
+int lanczos_device_free(int device, void* p) {
+    if (!p) return LANCZOS_OK;
+    DeviceGuard restore;
+    if (hipSetDevice(device) != hipSuccess) return LANCZOS_ERR_NO_DEVICE;
+    return hipFree(p) == hipSuccess ? LANCZOS_OK : LANCZOS_ERR_HIP;
+}
+
+int lanczos_device_copy(int device, void* dst, const void* src, size_t bytes, int to_device) {
+    if (!dst || !src) return LANCZOS_ERR_BAD_ARG;
+    DeviceGuard restore;
+    if (hipSetDevice(device) != hipSuccess) return LANCZOS_ERR_NO_DEVICE;
+    return hipMemcpy(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) == hipSuccess ? LANCZOS_OK : LANCZOS_ERR_HIP;
 }
 
 }  // extern "C"

@@ -4,9 +4,12 @@
  *
  *   lanczos_upscale <in.(png|ppm|pgm)> <out.(png|ppm|pgm)> [--scale N[/D]] [--a A] [--channels C]
  *                   [--exact | --hls] [--device D] [--repeat K]
- *                   [--devices 0-7 | 0,2,5] [--frames F] [--split frames|rows]     (several GPUs of one node, plain C:
+ *                   [--devices 0-7 | 0,2,5] [--frames F] [--split frames|rows] [--root]   (several GPUs of one node, plain C:
  *                   the image is replicated into a batch of F frames and the batch -- or every frame's rows -- is split
- *                   over the devices by lanczos_resample_multi_host; the first result frame is written)
+ *                   over the devices by lanczos_resample_multi_host; the first result frame is written.  --root: the batch
+ *                   is resident on the first device instead and travels by one RCCL scatter / gather over xGMI
+ *                   (lanczos_resample_multi_root); compute-only and exchange-inclusive rates are printed separately,
+ *                   SURVEY.md 8e "Reporting")
  *
  * load (interleaved u8 HWC, like stbi_load, full_TB.h:107) -> checks with the reference's messages and
  * EXIT_FAILURE (full_TB.h:110-123) -> "Scale:%d/%d, WIDTHS %d -> %d" (full_TB.h:124) -> the resample, through
@@ -30,7 +33,7 @@ static int ends_with(const char* s, const char* suf) {
 int main(int argc, char* argv[]) {
     const char *in_path = NULL, *out_path = NULL;
     int scale_n = 2, scale_d = 1, a = 3, want_channels = 3, exact = 0, hls = 0, device = 0, repeat = 1;
-    int devices[64], n_devices = 0, frames = 1, split = LANCZOS_SPLIT_FRAMES;
+    int devices[64], n_devices = 0, frames = 1, split = LANCZOS_SPLIT_FRAMES, root = 0;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--scale") && i + 1 < argc) {
             scale_d = 1;
@@ -47,6 +50,8 @@ int main(int argc, char* argv[]) {
             exact = 1;
         } else if (!strcmp(argv[i], "--hls")) {
             hls = 1;
+        } else if (!strcmp(argv[i], "--root")) {
+            root = 1;
         } else if (!strcmp(argv[i], "--frames") && i + 1 < argc) {
             frames = atoi(argv[++i]);
         } else if (!strcmp(argv[i], "--split") && i + 1 < argc) {
@@ -71,7 +76,7 @@ int main(int argc, char* argv[]) {
     }
     if (!in_path || !out_path) {
         fprintf(stderr, "usage: %s <in.png|ppm> <out.png|ppm> [--scale N[/D]] [--a A] [--channels C] [--exact|--hls] "
-                        "[--device D] [--repeat K] [--devices 0-7|0,2,5] [--frames F] [--split frames|rows]\n", argv[0]);
+                        "[--device D] [--repeat K] [--devices 0-7|0,2,5] [--frames F] [--split frames|rows] [--root]\n", argv[0]);
         return EXIT_FAILURE;
     }
     printf("Running full TB (%s)\n", lanczos_version());  /* main.cpp:16 */
@@ -107,6 +112,37 @@ int main(int argc, char* argv[]) {
             return EXIT_FAILURE;
         }
         for (int f = 0; f < frames; f++) memcpy(batch_in + (size_t)f * in_fb, img, in_fb);
+        if (root) {
+            /* the batch lives on the FIRST device; the other devices get their shares by one RCCL scatter and return them by one
+             * gather (over xGMI).  Two rates, never mixed: the resample step alone and the whole call. */
+            void *d_in = NULL, *d_out = NULL;
+            double cms = 0, tms = 0, cms_sum = 0, tms_sum = 0;
+            rc = lanczos_device_alloc(devices[0], &d_in, in_fb * frames);
+            if (rc == LANCZOS_OK) rc = lanczos_device_alloc(devices[0], &d_out, out_fb * frames);
+            if (rc == LANCZOS_OK) rc = lanczos_device_copy(devices[0], d_in, batch_in, in_fb * frames, 1);
+            if (rc == LANCZOS_OK) rc = lanczos_resample_multi_root(m, &d, d_in, d_out, frames, split, &cms, &tms); /* warm-up */
+            for (int k = 0; k < repeat && rc == LANCZOS_OK; k++) {
+                rc = lanczos_resample_multi_root(m, &d, d_in, d_out, frames, split, &cms, &tms);
+                cms_sum += cms;
+                tms_sum += tms;
+            }
+            if (rc == LANCZOS_OK) rc = lanczos_device_copy(devices[0], out, d_out, out_fb * frames, 0);
+            if (rc != LANCZOS_OK) {
+                int he = 0, re = 0, at = 0;
+                lanczos_multi_last_error(m, &he, &re, &at);
+                printf("lanczos failed: %s (hip error %d, rccl error %d at message %d)\n", lanczos_strerror(rc), he, re, at);
+                return EXIT_FAILURE;
+            }
+            const double mpix = frames * d.out_w * (double)d.out_h / 1e6;
+            printf("%dx%d->%dx%d_%d|%d_%d: %d frames resident on device %d, %d device(s), split by %s:\n"
+                   "  compute only            %.3f ms per batch (%.1f Mpix/s)\n"
+                   "  root scatter + gather   %.3f ms per batch (%.1f Mpix/s)\n", d.in_w, d.in_h, d.out_w, d.out_h, d.scale_n,
+                   d.scale_d, d.a, frames, devices[0], lanczos_multi_devices(m), split == LANCZOS_SPLIT_ROWS ? "rows" : "frames",
+                   cms_sum / repeat, mpix / (cms_sum / repeat) * 1e3, tms_sum / repeat, mpix / (tms_sum / repeat) * 1e3);
+            lanczos_device_free(devices[0], d_in);
+            lanczos_device_free(devices[0], d_out);
+            goto multi_done;
+        }
         rc = lanczos_resample_multi_host(m, &d, batch_in, out, frames, split); /* warm-up: plans, staging buffers */
         clock_gettime(CLOCK_MONOTONIC, &t0);
         for (int k = 0; k < repeat && rc == LANCZOS_OK; k++) rc = lanczos_resample_multi_host(m, &d, batch_in, out, frames, split);
@@ -120,6 +156,7 @@ int main(int argc, char* argv[]) {
                "(%.1f Mpix/s)\n", d.in_w, d.in_h, d.out_w, d.out_h, d.scale_n, d.scale_d, d.a, frames,
                lanczos_multi_devices(m), split == LANCZOS_SPLIT_ROWS ? "rows" : "frames", ms,
                frames * d.out_w * (double)d.out_h / ms / 1e3);
+    multi_done:
         for (int f = 1; f < frames; f++)
             if (memcmp(out, out + (size_t)f * out_fb, out_fb) != 0) {
                 printf("frame %d differs from frame 0\n", f);

@@ -92,6 +92,15 @@ def test_harness_multi_device_options(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         assert f"5 frames over 2 device(s), split by {split}" in r.stdout
         assert np.array_equal(_read_png(str(dst)), want)
+    # --root: the batch resident on the first device, lanczos_resample_multi_root (one device: no exchange partner; with more
+    # devices the RCCL scatter / gather runs -- unmeasured on this pool's one-GPU boxes), both rates printed separately
+    for split in ("frames", "rows"):
+        dst = tmp_path / f"root_{split}.png"
+        r = subprocess.run([os.path.join(PKG, "lanczos_upscale"), str(src), str(dst), "--exact", "--devices", "0", "--root",
+                            "--frames", "3", "--split", split], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "compute only" in r.stdout and "root scatter + gather" in r.stdout and "3 frames resident on device 0" in r.stdout
+        assert np.array_equal(_read_png(str(dst)), want)
     dst = tmp_path / "hls.png"                                         # --hls: the HLS-semantics mode through the harness
     r = subprocess.run([os.path.join(PKG, "lanczos_upscale"), str(src), str(dst), "--hls"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -40,6 +40,93 @@ def test_partition_rows_config5_and_tiny_frames():
     assert [L.partition_rows(d3, 4, i)[:2] for i in range(4)] == [(20 * i, 20) for i in range(4)]
 
 
+def _check_exchange(d, frames, split, n):
+    """Replays both message lists on numpy buffers: every peer ends up with exactly its share of the root's input, and the
+    root's output is tiled exactly once by the peers' shares (rank 0 computes in place on the root buffers)."""
+    bps = d.bytes_per_sample
+    in_pitch, out_pitch = d.in_w * d.channels * bps, d.out_w * d.channels * bps
+    in_frame, out_frame = in_pitch * d.in_h, out_pitch * d.out_h
+    rng = np.random.default_rng(7)
+    root_in = rng.integers(0, 256, frames * in_frame, dtype=np.uint8)
+    shares = []
+    for i in range(n):
+        if split == L.SPLIT_FRAMES:
+            f0, cnt = L.partition_frames(frames, n, i)
+            shares.append(dict(f0=f0, cnt=cnt, in_bytes=cnt * in_frame, out_bytes=cnt * out_frame))
+        else:
+            r0, rows, i0, irows = L.partition_rows(d, n, i)
+            shares.append(dict(r0=r0, rows=rows, i0=i0, irows=irows, in_bytes=frames * irows * in_pitch, out_bytes=frames * rows * out_pitch))
+    # ---- scatter
+    peer_in = [np.full(s["in_bytes"], 0xEE, np.uint8) for s in shares]
+    plan = L.exchange_plan(d, frames, split, n, 0)
+    for (src, dst, so, do, nb) in plan:
+        assert src == 0 and 1 <= dst < n and nb > 0
+        assert so + nb <= root_in.size and do + nb <= peer_in[dst].size
+        peer_in[dst][do:do + nb] = root_in[so:so + nb]
+    for i in range(1, n):
+        s = shares[i]
+        if split == L.SPLIT_FRAMES:
+            want = root_in[s["f0"] * in_frame:(s["f0"] + s["cnt"]) * in_frame]
+        else:
+            fr = root_in.reshape(frames, d.in_h, in_pitch)
+            want = fr[:, s["i0"]:s["i0"] + s["irows"]].reshape(-1)
+        assert np.array_equal(peer_in[i], want), (split, n, i)
+    # ---- gather: peers hold recognisable shards; the root's output must receive every byte outside rank 0's share exactly once
+    hits = np.zeros(frames * out_frame, np.int32)
+    root_out = np.zeros(frames * out_frame, np.uint8)
+    peer_out = [np.full(s["out_bytes"], i + 1, np.uint8) for i, s in enumerate(shares)]
+    for (src, dst, so, do, nb) in L.exchange_plan(d, frames, split, n, 1):
+        assert dst == 0 and 1 <= src < n and so + nb <= peer_out[src].size and do + nb <= root_out.size
+        root_out[do:do + nb] = peer_out[src][so:so + nb]
+        hits[do:do + nb] += 1
+    owner = np.zeros((frames, d.out_h, out_pitch), np.uint8)
+    for i, s in enumerate(shares):
+        if split == L.SPLIT_FRAMES:
+            owner[s["f0"]:s["f0"] + s["cnt"]] = i + 1
+        else:
+            owner[:, s["r0"]:s["r0"] + s["rows"]] = i + 1
+    owner = owner.reshape(-1)
+    assert np.all(owner >= 1)                                   # the shares cover the output
+    assert np.array_equal(hits, (owner != 1).astype(np.int32))  # every byte of a peer's share arrives once, rank 0's never
+    assert np.array_equal(root_out[owner != 1], owner[owner != 1])
+
+
+def test_root_exchange_message_lists_without_hardware():
+    """SURVEY.md 8e at n = 8 (and ragged cases): the scatter / gather lists of lanczos_resample_multi_root checked against
+    lanczos_partition_* by replaying them on host buffers -- the RCCL path itself has never run on more than one GPU."""
+    c2 = L.make_desc(192, 108, 3, 2, 1, 3)                      # config 4's shape, scaled down 10x
+    _check_exchange(c2, 64, L.SPLIT_FRAMES, 8)
+    _check_exchange(c2, 5, L.SPLIT_FRAMES, 8)                    # fewer frames than devices: empty shares send nothing
+    _check_exchange(c2, 3, L.SPLIT_ROWS, 8)
+    c5 = L.make_desc(384, 216, 4, 2, 1, 4, bytes_per_sample=2)   # config 5's shape, scaled down 10x
+    _check_exchange(c5, 2, L.SPLIT_ROWS, 8)
+    _check_exchange(c5, 1, L.SPLIT_ROWS, 5)
+    _check_exchange(L.make_desc(32, 10, 3, 2, 1, 3), 2, L.SPLIT_ROWS, 8)   # tiny frame: some strips are empty
+    _check_exchange(c2, 4, L.SPLIT_FRAMES, 1)                    # one device: no messages at all
+    assert L.exchange_plan(c2, 4, L.SPLIT_FRAMES, 1, 0) == [] and L.exchange_plan(c2, 4, L.SPLIT_ROWS, 1, 1) == []
+    # full-size config 4 / 5 message sizes (SURVEY.md 8e): 49.8 MB in / 199 MB out per peer; one strip per frame for config 5
+    full = L.make_desc(1920, 1080, 3, 2, 1, 3)
+    sc = L.exchange_plan(full, 64, L.SPLIT_FRAMES, 8, 0)
+    assert len(sc) == 7 and all(x[4] == 8 * 1920 * 1080 * 3 for x in sc)
+    ga = L.exchange_plan(full, 64, L.SPLIT_FRAMES, 8, 1)
+    assert len(ga) == 7 and all(x[4] == 8 * 3840 * 2160 * 3 for x in ga)
+    with pytest.raises(L.LanczosError):
+        L.exchange_plan(full, 0, L.SPLIT_FRAMES, 8, 0)
+
+
+def test_root_exchange_group_handling_native(tmp_path):
+    """lz::exchange_run (what issues the ncclSend / ncclRecv group) with recording and failing stubs, compiled with g++: every
+    return code is looked at, nothing is queued after the first failure, and an opened group is closed on every path."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "exchange_check")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-I" + os.path.join(root, "lanczos-hls_amd", "csrc"),
+                    os.path.join(root, "tests", "native", "exchange_check.cpp"), "-o", exe], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "exchange_run: all cases ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_multi_host_path_two_contexts_on_one_device():
     frames = np.stack([P.noise(72, 96, 3, seed=500 + i) for i in range(5)])
