@@ -82,6 +82,10 @@ typedef struct lanczos_desc {
      * frame.  With a strip, `in` points at input row lanczos_strip_input_rows().in_row0 and `out`
      * at output row out_row0; both keep the full-frame row pitch. */
     int32_t out_row0, out_rows;
+    /* reserved[0] = BIT_PRECISION (params.h; lanczos.h:74-81) of LANCZOS_MODE_HLS's fixed-point emulation: 0 = ideal arithmetic
+     * (default), 1..20 = weights cut to BP fractional bits (kernel_t = ap_fixed<8+BP,8>) and the horizontal accumulator cut
+     * to BP fractional bits after every tap (num_el_t = ap_fixed<10+BP,10>), AP_TRN / AP_WRAP as the declarations default to.
+     * 8-bit samples, HLS mode only.  Parity unpinned (the hardware's ROM comes out of hls::sinpi).  reserved[1..2]: 0. */
     int32_t reserved[3];
 } lanczos_desc;
 

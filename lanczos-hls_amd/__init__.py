@@ -140,12 +140,14 @@ def _check(rc, what):
 
 
 def make_desc(in_w, in_h, channels, scale_n, scale_d, a, bytes_per_sample=1, mode=MODE_LSB1,
-              out_row0=0, out_rows=0):
+              out_row0=0, out_rows=0, bit_precision=0):
+    """bit_precision: BIT_PRECISION of the HLS mode's fixed-point emulation (lanczos_desc.reserved[0]; 0 = ideal arithmetic)."""
     d = Desc()
     _check(_lib().lanczos_desc_init(ctypes.byref(d), in_w, in_h, channels, bytes_per_sample,
                                     scale_n, scale_d, a), "lanczos_desc_init")
     d.mode = mode
     d.out_row0, d.out_rows = out_row0, out_rows
+    d.reserved[0] = bit_precision
     _check(_lib().lanczos_validate(ctypes.byref(d)), "lanczos_validate")
     return d
 
@@ -225,16 +227,16 @@ class Context:
             pass
 
     # -- host buffers: the drop-in for lanczos(stream_in, stream_out) at full_TB.h:140
-    def resample(self, img, scale_n, scale_d, a, mode=MODE_LSB1, out=None):
+    def resample(self, img, scale_n, scale_d, a, mode=MODE_LSB1, out=None, bit_precision=0):
         """img: [H][W][C] (or [F][H][W][C]) uint8/uint16, stb interleaved layout -> scaled image(s).
-        `out`: optional preallocated result (e.g. a PinnedArray's .array)."""
+        `out`: optional preallocated result (e.g. a PinnedArray's .array).  bit_precision: MODE_HLS only (make_desc)."""
         img = np.ascontiguousarray(img)
         batched = img.ndim == 4
         x = img if batched else img[None]
         if x.ndim != 4 or x.dtype not in (np.uint8, np.uint16):
             raise LanczosError(ERR_BAD_ARG, "resample: expected [H][W][C] uint8/uint16")
         f, h, w, c = x.shape
-        d = make_desc(w, h, c, scale_n, scale_d, a, x.dtype.itemsize, mode)
+        d = make_desc(w, h, c, scale_n, scale_d, a, x.dtype.itemsize, mode, bit_precision=bit_precision)
         if out is None:
             out = np.empty((f, d.out_h, d.out_w, c), dtype=x.dtype)
         else:

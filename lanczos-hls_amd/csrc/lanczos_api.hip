@@ -97,7 +97,7 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
     memset(&key, 0, sizeof(key));
     const bool hls = d->mode == LANCZOS_MODE_HLS;
     key = PlanKey{d->in_w, d->in_h, d->out_w, d->out_h, d->channels, d->bytes_per_sample,
-                  d->scale_n, d->scale_d, d->a, hls ? 1 : 0};
+                  d->scale_n, d->scale_d, d->a, hls ? 1 + d->reserved[0] : 0};
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) {
         *out = it->second;
@@ -106,8 +106,8 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
     Plan* p = new (std::nothrow) Plan();
     if (!p) return LANCZOS_ERR_NOMEM;
     if (hls) {  // ROM weights, exact stepping, no in-place prefix (lanczos_hls.hpp)
-        lz::build_axis_hls(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &p->H);
-        lz::build_axis_hls(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &p->V);
+        lz::build_axis_hls(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &p->H, d->reserved[0]);
+        lz::build_axis_hls(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &p->V, d->reserved[0]);
     } else {
         lz::build_axis(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &p->H);
         lz::build_axis(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &p->V);
@@ -306,7 +306,7 @@ int lanczos_taps_host(const lanczos_desc* d, int axis, int32_t* first, double* w
     if (!first || !weights || (axis != 0 && axis != 1)) return LANCZOS_ERR_BAD_ARG;
     lz::AxisTaps t;
     if (d->mode == LANCZOS_MODE_HLS)
-        lz::build_axis_hls(axis == 0 ? d->in_w : d->in_h, axis == 0 ? d->out_w : d->out_h, d->scale_n, d->scale_d, d->a, &t);
+        lz::build_axis_hls(axis == 0 ? d->in_w : d->in_h, axis == 0 ? d->out_w : d->out_h, d->scale_n, d->scale_d, d->a, &t, d->reserved[0]);
     else if (axis == 0)
         lz::build_axis(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &t);
     else
@@ -491,7 +491,9 @@ int lanczos_force_kernel(lanczos_ctx* ctx, int family) {
 // instance for this (sample type, scale, a) -- the caller falls back to the serial k_prefix.
 static hipError_t launch_prefix_side(lanczos_ctx* ctx, const lanczos_desc* d, const lz::FrameGeom& g, const Plan* p,
                                      hipStream_t stream, bool same_stream) {
-#define LZ_PREFIX_REG_CONFIGS(X) X(uint8_t, 2, 3) X(uint8_t, 3, 3) X(uint8_t, 2, 2) X(uint8_t, 2, 4) X(uint16_t, 2, 4) X(uint16_t, 2, 3)
+#define LZ_PREFIX_REG_CONFIGS(X)                                                                                        \
+    X(uint8_t, 2, 2) X(uint8_t, 2, 3) X(uint8_t, 2, 4) X(uint8_t, 3, 2) X(uint8_t, 3, 3) X(uint8_t, 3, 4) X(uint8_t, 4, 2) \
+    X(uint8_t, 4, 3) X(uint8_t, 4, 4) X(uint16_t, 2, 3) X(uint16_t, 2, 4) X(uint16_t, 3, 3) X(uint16_t, 3, 4)
     bool have = false;
 #define X(T, S, A)                                                                                                    \
     if (d->bytes_per_sample == (int)sizeof(T) && d->scale_n == S && d->a == A && p->prefix.K == lz::prefix_K(S, A) && \
@@ -566,6 +568,7 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
     g.out_rows = rows;
     g.skip_rows = has_prefix ? p->prefix.K : 0;
     g.frames = frames;
+    g.hls_bp = d->mode == LANCZOS_MODE_HLS ? d->reserved[0] : 0;
     {
         static const int dbg = getenv("LANCZOS_DEBUG_SKIP") ? atoi(getenv("LANCZOS_DEBUG_SKIP")) : 0;
         g.debug_skip = dbg;

@@ -612,17 +612,22 @@ inline hipError_t fast_launch_t(const lanczos_desc& d, const FrameGeom& g, const
     return hipGetLastError();
 }
 
-// the instantiated configurations: (sample type, channels, scale, a)
-#define LZ_FAST_CONFIGS(X) \
-    X(uint8_t, 3, 2, 3)    \
-    X(uint8_t, 3, 3, 3)    \
-    X(uint8_t, 3, 2, 2)    \
-    X(uint8_t, 3, 2, 4)    \
-    X(uint8_t, 4, 2, 4)    \
-    X(uint8_t, 4, 2, 3)    \
-    X(uint8_t, 1, 2, 3)    \
-    X(uint16_t, 4, 2, 4)   \
-    X(uint16_t, 3, 2, 3)
+// The instantiated configurations: (sample type, channels, scale, a) -- every integer scale 2..4 of the reference's params.h
+// space (lanczos.h:9-31: NUM_CHANNELS 1 / 3 / 4, LANCZOS_A 2..4) for 8-bit samples, scales 2 and 3 with a = 3, 4 for 16-bit ones.
+// Four groups = four translation units (csrc/lanczos_inst.hip compiled with -DLZ_INST_GROUP=0..3, in parallel).
+#define LZ_FAST_CONFIGS_G0(X) /* 8-bit, 2x */ \
+    X(uint8_t, 3, 2, 3) X(uint8_t, 3, 2, 2) X(uint8_t, 3, 2, 4) X(uint8_t, 4, 2, 2) X(uint8_t, 4, 2, 3) X(uint8_t, 4, 2, 4) \
+    X(uint8_t, 1, 2, 2) X(uint8_t, 1, 2, 3) X(uint8_t, 1, 2, 4)
+#define LZ_FAST_CONFIGS_G1(X) /* 8-bit, 3x */ \
+    X(uint8_t, 3, 3, 3) X(uint8_t, 3, 3, 2) X(uint8_t, 3, 3, 4) X(uint8_t, 4, 3, 2) X(uint8_t, 4, 3, 3) X(uint8_t, 4, 3, 4) \
+    X(uint8_t, 1, 3, 2) X(uint8_t, 1, 3, 3) X(uint8_t, 1, 3, 4)
+#define LZ_FAST_CONFIGS_G2(X) /* 8-bit, 4x */ \
+    X(uint8_t, 3, 4, 3) X(uint8_t, 3, 4, 2) X(uint8_t, 3, 4, 4) X(uint8_t, 4, 4, 2) X(uint8_t, 4, 4, 3) X(uint8_t, 4, 4, 4) \
+    X(uint8_t, 1, 4, 2) X(uint8_t, 1, 4, 3) X(uint8_t, 1, 4, 4)
+#define LZ_FAST_CONFIGS_G3(X) /* 16-bit */ \
+    X(uint16_t, 4, 2, 4) X(uint16_t, 3, 2, 3) X(uint16_t, 4, 2, 3) X(uint16_t, 3, 2, 4) \
+    X(uint16_t, 3, 3, 3) X(uint16_t, 3, 3, 4) X(uint16_t, 4, 3, 3) X(uint16_t, 4, 3, 4)
+#define LZ_FAST_CONFIGS(X) LZ_FAST_CONFIGS_G0(X) LZ_FAST_CONFIGS_G1(X) LZ_FAST_CONFIGS_G2(X) LZ_FAST_CONFIGS_G3(X)
 
 inline bool fast_supports(const lanczos_desc& d, const FrameGeom& g) {
     if (d.scale_d != 1) return false;
@@ -635,13 +640,21 @@ inline bool fast_supports(const lanczos_desc& d, const FrameGeom& g) {
     return false;
 }
 
+// one dispatcher per group, defined in lanczos_inst.hip (hipErrorNotSupported: not one of the group's configurations)
+#define LZ_DECLARE_FAST_GROUP(G)                                                                                         \
+    hipError_t fast_launch_g##G(const lanczos_desc& d, const FrameGeom& g, const TapTables& t, const FastConsts& fc, hipStream_t stream);
+LZ_DECLARE_FAST_GROUP(0)
+LZ_DECLARE_FAST_GROUP(1)
+LZ_DECLARE_FAST_GROUP(2)
+LZ_DECLARE_FAST_GROUP(3)
+#undef LZ_DECLARE_FAST_GROUP
+
 inline hipError_t fast_launch(const lanczos_desc& d, const FrameGeom& g, const TapTables& t, const FastConsts& fc,
                               hipStream_t stream) {
-#define X(T, C, S, A)                                                                               \
-    if (d.bytes_per_sample == (int)sizeof(T) && d.channels == C && d.scale_n == S && d.a == A)      \
-        return fast_launch_t<T, C, S, A>(d, g, t, fc, stream);
-    LZ_FAST_CONFIGS(X)
-#undef X
+    if (d.bytes_per_sample == 2) return fast_launch_g3(d, g, t, fc, stream);
+    if (d.scale_n == 2) return fast_launch_g0(d, g, t, fc, stream);
+    if (d.scale_n == 3) return fast_launch_g1(d, g, t, fc, stream);
+    if (d.scale_n == 4) return fast_launch_g2(d, g, t, fc, stream);
     return hipErrorNotSupported;
 }
 

@@ -7,8 +7,15 @@
 //   * de-ringing: each pass clamps its sum to [min, max] of the two centre taps   worker.cpp:66-74, :103-111
 //   * the vertical result stays a real number between the passes (num_t), only the final store truncates  worker.cpp:118-130
 // The hardware computes in ap_fixed (BIT_PRECISION fractional bits) with a fixed-point phase stepper; this mode computes the
-// same algorithm in f64 with exact stepping (floor(o*D/N)).  PARITY UNPINNED: the HLS path cannot be built here (Xilinx
-// headers absent) and the reference holds no outputs of it; the checker is oracle/lanczos_hls_model.c, bit for bit.
+// same algorithm in f64 with exact stepping (floor(o*D/N)) and, on request (lanczos_desc.reserved[0] = BIT_PRECISION, 8-bit
+// samples), with the quantisation the ap_fixed declarations imply (lanczos.h:74-81, defaults AP_TRN / AP_WRAP):
+//   ROM entries cut to BP fractional bits (host tables)      kernel_t  = ap_fixed<8+BP,8>,  kernel.cpp:42
+//   V pass: kernel_t x byte is exact, the sum wraps at 10 integer bits                     worker.cpp:58-64
+//   H pass: kernel_t x num_el_t has 2 BP fractional bits, every `acc +=` keeps BP of them  worker.cpp:95-101
+// (all values are multiples of 2^-2BP below 2^10: exact in f64 for BP <= 20).  What stays different from the hardware: its
+// ROM comes out of hls::sinpi in kernel_t arithmetic (unknown low bits), its phase stepper is fixed point.
+// PARITY UNPINNED: the HLS path cannot be built here (Xilinx headers absent) and the reference holds no outputs of it; the
+// checker is oracle/lanczos_hls_model.c, bit for bit.
 //
 // One workgroup = 64 output pixels x 8 output rows of one frame:
 //   1. for every (row of the tile, input column the tile's horizontal windows touch, channel): the clamped vertical sum, f64,
@@ -30,7 +37,14 @@ template <typename T>
 __global__ __launch_bounds__(kHlsThreads) void k_hls(FrameGeom g, TapTables t) {
     __shared__ double vbuf[kHlsTileH][kHlsMaxCols * 4];  // [tile row][input column - q0][channel]
 
-    const int taps = 2 * g.a, A = g.a, C = g.channels;
+    const int taps = 2 * g.a, A = g.a, C = g.channels, bp = g.hls_bp;
+    const double fx_s = __builtin_ldexp(1.0, bp), fx_is = __builtin_ldexp(1.0, -bp);
+    auto wrap10 = [](double x) {  // AP_WRAP of ap_fixed<10+BP,10>: never taken for clamped 8-bit data, kept for fidelity
+        if (x >= -512.0 && x < 512.0) return x;
+        double r = __builtin_fmod(x + 512.0, 1024.0);
+        if (r < 0) r += 1024.0;
+        return r - 512.0;
+    };
     const int tiles_x = (g.out_w + kHlsTileW - 1) / kHlsTileW;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int frame = blockIdx.y;
@@ -65,6 +79,7 @@ __global__ __launch_bounds__(kHlsThreads) void k_hls(FrameGeom g, TapTables t) {
                     hi = px > hi ? px : hi;
                 }
             }
+            if (bp > 0) acc = wrap10(acc);
             v = acc < lo ? lo : (acc > hi ? hi : acc);               // worker.cpp:66-74
         }
         vbuf[r][qi * C + c] = v;
@@ -82,7 +97,8 @@ __global__ __launch_bounds__(kHlsThreads) void k_hls(FrameGeom g, TapTables t) {
         for (int k = 0; k < taps; k++) {
             const int q = first + k;            // < 0: zero (worker.cpp:256-265); > in_w-1: clamped in step 1 (:244)
             const double px = vbuf[r][(q - q0) * C + c];
-            acc += w[k] * px;                                         // worker.cpp:95-101
+            if (bp > 0) acc = wrap10(__builtin_floor((acc + w[k] * px) * fx_s) * fx_is);  // num_el_t acc += kernel_t * num_el_t (AP_TRN)
+            else acc += w[k] * px;                                    // worker.cpp:95-101
             if (k == A - 1) lo = hi = px;
             if (k == A) {
                 lo = px < lo ? px : lo;

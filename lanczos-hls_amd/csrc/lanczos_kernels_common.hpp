@@ -38,6 +38,7 @@ struct FrameGeom {
     // `prefix_blocks_per_frame` workgroups per frame that produce output rows [0, prefix_K) (the in-place prefix, see
     // k_prefix); prefix_K == 0: a separate k_prefix launch does that
     int n_main, wg_per_frame, prefix_blocks_per_frame, prefix_K, prefix_M, prefix_M2;
+    int hls_bp;           // k_hls only: BIT_PRECISION of the fixed-point emulation (0 = ideal arithmetic)
     int debug_skip;       // ablation bits for profiling builds (0 in production): 1 H-pass, 2 fix-up, 4 V-pass, 8 stores, 16 loads
     const WgEntry* wg_tab; // k_march only: [n_main][wg_segs] share of every marching workgroup, indexed by the hardware block id
     int wg_segs;           // segments (table entries) per workgroup

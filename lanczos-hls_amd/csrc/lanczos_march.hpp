@@ -1584,14 +1584,23 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     return hipGetLastError();
 }
 
+struct WgTabCache;
+#define LZ_DECLARE_MARCH_GROUP(G)                                                                                                  \
+    hipError_t march_launch_g##G(const lanczos_desc& d, const FrameGeom& g, const TapTables& t, const FastConsts& fc, hipStream_t stream, \
+                                 bool* prefix_fused, WgTabCache* cache, bool query_only);
+LZ_DECLARE_MARCH_GROUP(0)
+LZ_DECLARE_MARCH_GROUP(1)
+LZ_DECLARE_MARCH_GROUP(2)
+LZ_DECLARE_MARCH_GROUP(3)
+#undef LZ_DECLARE_MARCH_GROUP
+
 inline hipError_t march_launch(const lanczos_desc& d, const FrameGeom& g, const TapTables& t, const FastConsts& fc,
                                hipStream_t stream, bool* prefix_fused, WgTabCache* cache, bool query_only = false) {
     *prefix_fused = false;
-#define X(T, C, S, A)                                                                               \
-    if (d.bytes_per_sample == (int)sizeof(T) && d.channels == C && d.scale_n == S && d.a == A)      \
-        return march_launch_t<T, C, S, A>(d, g, t, fc, stream, prefix_fused, query_only, cache);
-    LZ_FAST_CONFIGS(X)
-#undef X
+    if (d.bytes_per_sample == 2) return march_launch_g3(d, g, t, fc, stream, prefix_fused, cache, query_only);
+    if (d.scale_n == 2) return march_launch_g0(d, g, t, fc, stream, prefix_fused, cache, query_only);
+    if (d.scale_n == 3) return march_launch_g1(d, g, t, fc, stream, prefix_fused, cache, query_only);
+    if (d.scale_n == 4) return march_launch_g2(d, g, t, fc, stream, prefix_fused, cache, query_only);
     return hipErrorNotSupported;
 }
 

@@ -56,7 +56,7 @@ double hls_rom(int k, int a, int scale_n) {
     return c * s1 * s2 / (x * x);
 }
 
-void build_axis_hls(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* t) {
+void build_axis_hls(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* t, int bit_precision) {
     t->in_n = in_n;
     t->out_n = out_n;
     t->a = a;
@@ -68,7 +68,9 @@ void build_axis_hls(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTa
         for (int k = 0; k < 2 * a; k++) {
             long long idx = (long long)o * scale_d - (long long)(first + k) * scale_n;  // kernel.cpp:56
             if (idx < 0) idx = -idx;
-            t->w[(size_t)o * 2 * a + k] = idx > (long long)a * scale_n ? 0.0 : hls_rom((int)idx, a, scale_n);
+            double w = idx > (long long)a * scale_n ? 0.0 : hls_rom((int)idx, a, scale_n);
+            if (bit_precision > 0) w = std::ldexp(std::floor(std::ldexp(w, bit_precision)), -bit_precision);  // (kernel_t)..., kernel.cpp:42
+            t->w[(size_t)o * 2 * a + k] = w;
         }
     }
 }
@@ -99,6 +101,9 @@ int validate(const lanczos_desc* d) {
     if (d->a < 2 || d->a > kMaxA) return LANCZOS_ERR_BAD_ARG;
     if (d->scale_n <= 0 || d->scale_d <= 0) return LANCZOS_ERR_BAD_ARG;
     if (d->mode != LANCZOS_MODE_LSB1 && d->mode != LANCZOS_MODE_EXACT && d->mode != LANCZOS_MODE_HLS) return LANCZOS_ERR_BAD_ARG;
+    // reserved[0] = BIT_PRECISION of the HLS mode's fixed-point emulation: 0 (ideal arithmetic) .. 20, 8-bit samples only
+    if (d->reserved[0] < 0 || d->reserved[0] > 20) return LANCZOS_ERR_BAD_ARG;
+    if (d->reserved[0] > 0 && (d->mode != LANCZOS_MODE_HLS || d->bytes_per_sample != 1)) return LANCZOS_ERR_BAD_ARG;
     // the harness rejects images whose size is not the compiled-in one (full_TB.h:115-118);
     // here: the output must be the input scaled by N/D (integer division, as OUT_WIDTH = IN_WIDTH*3)
     if ((long long)d->in_w * d->scale_n / d->scale_d != d->out_w) return LANCZOS_ERR_BAD_ARG;

@@ -34,7 +34,8 @@ void build_axis(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* 
 // ROM[k] = a/pi^2 * sinpi(k/N) * sinpi(k/(aN)) / (k/N)^2 at k = |o*D - i*N| (1 at k = 0, exactly 0 at whole-pixel
 // distances and at k = a*N).  NO zeroing of out-of-range taps: the HLS borders substitute samples, not weights.
 double hls_rom(int k, int a, int scale_n);
-void build_axis_hls(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* t);
+// bit_precision > 0: ROM entries truncated to that many fractional bits (kernel_t = ap_fixed<8+BP,8>, lanczos.h:80, AP_TRN)
+void build_axis_hls(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTaps* t, int bit_precision = 0);
 
 struct PrefixInfo {
     int K = 0;   // output rows [0,K) read rows i > xx, i.e. already-written OUTPUT rows (full_TB.h:67-77)

@@ -42,7 +42,26 @@ typedef struct {
     void* out;
     int bytes;
     int y0, y1;
+    int bp; /* BIT_PRECISION of the fixed-point emulation, 0 = ideal arithmetic */
 } hls_job;
+
+/* ---- fixed-point emulation (lanczos.h:74-81; ap_fixed defaults: AP_TRN quantisation = truncation towards minus infinity,
+ * AP_WRAP overflow).  Everything is a multiple of 2^-bp (or 2^-2bp inside one accumulation step) of magnitude < 2^10, exact in
+ * double for bp <= 20.
+ *   kernel_t  = ap_fixed<8+BP, 8>    a ROM entry keeps BP fractional bits
+ *   num_el_t  = ap_fixed<10+BP, 10>  accumulators and the value between the passes keep BP fractional bits, 10 integer bits */
+static double fx_trn(double x, int bp) { return ldexp(floor(ldexp(x, bp)), -bp); }
+static double fx_wrap10(double x, int bp) { /* two's-complement wrap of a multiple of 2^-bp into [-512, 512) */
+    (void)bp;
+    if (x >= -512.0 && x < 512.0) return x;
+    double r = fmod(x + 512.0, 1024.0);
+    if (r < 0) r += 1024.0;
+    return r - 512.0;
+}
+double oracle_hls_weight_fx(int i, int o, int a, int scale_n, int scale_d, int bp) {
+    const double w = oracle_hls_weight(i, o, a, scale_n, scale_d);
+    return bp > 0 ? fx_trn(w, bp) : w; /* (kernel_t)raw_lanczos_kernel(...), kernel.cpp:42 */
+}
 
 #define HLS_MAX_TAPS 16
 
@@ -52,7 +71,7 @@ typedef struct {
 #define HLS_DEFINE(T, SFX)                                                                                             \
     static void hls_rows_##SFX(const hls_job* j) {                                                                    \
         const oracle_cfg* c = j->c;                                                                                    \
-        const int C = c->channels, a = c->a, taps = 2 * a, W = c->in_w, H = c->in_h;                                  \
+        const int C = c->channels, a = c->a, taps = 2 * a, W = c->in_w, H = c->in_h, bp = j->bp;                      \
         const T* in = (const T*)j->in;                                                                                 \
         T* out = (T*)j->out;                                                                                           \
         double* vrow = (double*)malloc(sizeof(double) * (size_t)W * C);                                                \
@@ -64,7 +83,7 @@ typedef struct {
             int rr[HLS_MAX_TAPS];                                                                                       \
             for (int k = 0; k < taps; k++) {                                                                           \
                 const int r = fy - a + 1 + k;                                                                          \
-                wv[k] = oracle_hls_weight(r, y, a, c->scale_n, c->scale_d);                                            \
+                wv[k] = oracle_hls_weight_fx(r, y, a, c->scale_n, c->scale_d, bp);                                     \
                 rr[k] = r;                                                                                             \
             }                                                                                                          \
             for (int i = 0; i < W * C; i++) {                                                                          \
@@ -73,23 +92,28 @@ typedef struct {
                     const int r = rr[k];                                                                               \
                     px[k] = r < 0 ? 0.0 : (double)in[(size_t)(r > H - 1 ? H - 1 : r) * W * C + i];                    \
                 }                                                                                                      \
-                double acc = 0;                                                                                        \
-                for (int k = 0; k < taps; k++) acc += wv[k] * px[k];       /* worker.cpp:58-64 */                      \
+                double acc = 0; /* kernel_t x byte: the product has BP fractional bits, nothing is cut (worker.cpp:58-64) */ \
+                for (int k = 0; k < taps; k++) acc += wv[k] * px[k];                                                   \
+                if (bp > 0) acc = fx_wrap10(acc, bp);                                                                  \
                 const double lo = ORC_HLS_MIN(px[a - 1], px[a]), hi = ORC_HLS_MAX(px[a - 1], px[a]);                   \
                 vrow[i] = acc < lo ? lo : (acc > hi ? hi : acc);           /* worker.cpp:66-74 */                      \
             }                                                                                                          \
             for (int x = 0; x < c->out_w; x++) {                                                                       \
                 const int fx = (int)(((long long)x * c->scale_d) / c->scale_n);                                        \
                 double wh[HLS_MAX_TAPS];                                                                                \
-                for (int k = 0; k < taps; k++) wh[k] = oracle_hls_weight(fx - a + 1 + k, x, a, c->scale_n, c->scale_d); \
+                for (int k = 0; k < taps; k++) wh[k] = oracle_hls_weight_fx(fx - a + 1 + k, x, a, c->scale_n, c->scale_d, bp); \
                 for (int ch = 0; ch < C; ch++) {                                                                       \
                     double px[HLS_MAX_TAPS];                                                                            \
                     for (int k = 0; k < taps; k++) {                                                                   \
                         const int q = fx - a + 1 + k;  /* left: zeros (worker.cpp:256-265); right: last again (:244) */ \
                         px[k] = q < 0 ? 0.0 : vrow[(size_t)(q > W - 1 ? W - 1 : q) * C + ch];                          \
                     }                                                                                                  \
-                    double acc = 0;                                                                                    \
-                    for (int k = 0; k < taps; k++) acc += wh[k] * px[k];   /* worker.cpp:95-101 */                     \
+                    double acc = 0; /* kernel_t x num_el_t has 2 BP fractional bits; `acc +=` stores BP of them (AP_TRN), :95-101 */ \
+                    if (bp > 0) {                                                                                      \
+                        for (int k = 0; k < taps; k++) acc = fx_wrap10(fx_trn(acc + wh[k] * px[k], bp), bp);           \
+                    } else {                                                                                           \
+                        for (int k = 0; k < taps; k++) acc += wh[k] * px[k];                                           \
+                    }                                                                                                  \
                     const double lo = ORC_HLS_MIN(px[a - 1], px[a]), hi = ORC_HLS_MAX(px[a - 1], px[a]);               \
                     const double v = acc < lo ? lo : (acc > hi ? hi : acc);/* worker.cpp:103-111 */                    \
                     out[((size_t)y * c->out_w + x) * C + ch] = (T)floor(v);/* worker.cpp:118-130: truncation */        \
@@ -111,7 +135,8 @@ static void* hls_thread(void* p) {
     return NULL;
 }
 
-static int hls_run(const oracle_cfg* c, const void* in, void* out, int bytes, int threads) {
+static int hls_run(const oracle_cfg* c, const void* in, void* out, int bytes, int threads, int bp) {
+    if (bp < 0 || bp > 20 || (bp > 0 && bytes != 1)) return -3;
     if (!c || !in || !out || c->in_w <= 0 || c->in_h <= 0 || c->out_w <= 0 || c->out_h <= 0 || c->channels <= 0 ||
         c->a <= 0 || 2 * c->a > HLS_MAX_TAPS || c->scale_n <= 0 || c->scale_d <= 0)
         return -1;
@@ -125,6 +150,7 @@ static int hls_run(const oracle_cfg* c, const void* in, void* out, int bytes, in
         jobs[t].in = in;
         jobs[t].out = out;
         jobs[t].bytes = bytes;
+        jobs[t].bp = bp;
         jobs[t].y0 = (int)((long long)c->out_h * t / threads);
         jobs[t].y1 = (int)((long long)c->out_h * (t + 1) / threads);
     }
@@ -139,8 +165,11 @@ static int hls_run(const oracle_cfg* c, const void* in, void* out, int bytes, in
 }
 
 int oracle_hls_expected_hwc_u8(const oracle_cfg* cfg, const uint8_t* in, uint8_t* out, int threads) {
-    return hls_run(cfg, in, out, 1, threads);
+    return hls_run(cfg, in, out, 1, threads, 0);
 }
 int oracle_hls_expected_hwc_u16(const oracle_cfg* cfg, const uint16_t* in, uint16_t* out, int threads) {
-    return hls_run(cfg, in, out, 2, threads);
+    return hls_run(cfg, in, out, 2, threads, 0);
+}
+int oracle_hls_expected_hwc_u8_fx(const oracle_cfg* cfg, const uint8_t* in, uint8_t* out, int threads, int bit_precision) {
+    return hls_run(cfg, in, out, 1, threads, bit_precision);
 }

@@ -19,8 +19,14 @@
  *   between      the vertical result stays a (clamped) real number          worker.cpp:45-78 (num_t out)
  *   store        truncation to the integer sample                          worker.cpp:118-130 (clamp_to_byte)
  *   accumulation acc += kern[i] * px[i], i ascending                        worker.cpp:58-64, :95-101
- * Differences from the hardware that remain: no BIT_PRECISION quantisation of weights / accumulators, exact phase
- * stepping (floor(o*D/N) instead of the fixed-point fractional test worker.cpp:140,234).
+ * Fixed-point emulation (the _fx entry, bit_precision = BP > 0, 8-bit samples): what the ap_fixed declarations of
+ * lanczos.h:74-81 imply under their defaults (AP_TRN: quantisation by truncation towards minus infinity, AP_WRAP):
+ *   ROM entries keep BP fractional bits                  kernel_t = ap_fixed<8+BP,8>, kernel.cpp:42
+ *   vertical pass: kernel_t x byte products are exact, the sum lives in num_el_t = ap_fixed<10+BP,10>   worker.cpp:58-64
+ *   horizontal pass: kernel_t x num_el_t has 2 BP fractional bits, every `acc +=` stores BP of them      worker.cpp:95-101
+ * Differences from the hardware that REMAIN: the ROM is truncated from the ideal L(k/N), not from hls::sinpi's fixed-point
+ * result (kernel.cpp:12-18 evaluates the formula in kernel_t arithmetic: unknown low bits), and the phase stepping is exact
+ * (floor(o*D/N) instead of the fixed-point fractional test worker.cpp:140,234).  Still PARITY UNPINNED.
  */
 #ifndef LANCZOS_HLS_MODEL_H
 #define LANCZOS_HLS_MODEL_H
@@ -41,6 +47,9 @@ double oracle_hls_weight(int i, int o, int a, int scale_n, int scale_d);
 /* interleaved [H][W][C] in -> [OUT_H][OUT_W][C] out; cfg as for the software-path oracle */
 int oracle_hls_expected_hwc_u8(const oracle_cfg* cfg, const uint8_t* in, uint8_t* out, int threads);
 int oracle_hls_expected_hwc_u16(const oracle_cfg* cfg, const uint16_t* in, uint16_t* out, int threads);
+/* the same with BIT_PRECISION fractional bits (1..20; 0 = the ideal arithmetic above), 8-bit samples */
+int oracle_hls_expected_hwc_u8_fx(const oracle_cfg* cfg, const uint8_t* in, uint8_t* out, int threads, int bit_precision);
+double oracle_hls_weight_fx(int i, int o, int a, int scale_n, int scale_d, int bit_precision);
 
 #ifdef __cplusplus
 }

@@ -124,12 +124,21 @@ def expected_hwc_u16(c, img, threads=1):
     return out
 
 
-def hls_expected_hwc(c, img, threads=1):
+def hls_expected_hwc(c, img, threads=1, bit_precision=0):
     """oracle/lanczos_hls_model.c: the HLS pipeline's semantics (V-then-H, ROM weights, de-ring clamps, zero / repeat
-    borders) in ideal arithmetic.  PARITY UNPINNED by the reference."""
+    borders) in ideal arithmetic, or (bit_precision > 0, 8-bit samples) with the ap_fixed quantisation of lanczos.h:74-81.
+    PARITY UNPINNED by the reference."""
     img = np.ascontiguousarray(img)
     assert img.shape == (c.in_h, c.in_w, c.channels) and img.dtype in (np.uint8, np.uint16)
     out = np.empty((c.out_h, c.out_w, c.channels), dtype=img.dtype)
+    if bit_precision:
+        assert img.dtype == np.uint8
+        fx = lib().oracle_hls_expected_hwc_u8_fx
+        fx.restype = ctypes.c_int
+        fx.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        rc = fx(ctypes.cast(ctypes.byref(c), ctypes.c_void_p), img.ctypes.data, out.ctypes.data, threads, bit_precision)
+        assert rc == 0, rc
+        return out
     fn = lib().oracle_hls_expected_hwc_u8 if img.dtype == np.uint8 else lib().oracle_hls_expected_hwc_u16
     rc = fn(ctypes.byref(c), img.ctypes.data, out.ctypes.data, threads)
     assert rc == 0, rc

@@ -87,6 +87,58 @@ def test_model_equals_plain_separable_sum_where_nothing_clamps():
             assert abs(out[y, x] - np.floor(s + 1e-9)) <= 1 and abs(out[y, x] - s) < 1.0 + 1e-9
 
 
+def test_fixed_point_emulation_properties():
+    """BIT_PRECISION emulation (lanczos.h:74-81, AP_TRN / AP_WRAP; PARITY UNPINNED -- the hardware's ROM comes out of hls::sinpi):
+      * ROM entries are the ideal ones cut to BP fractional bits, towards minus infinity (kernel_t = ap_fixed<8+BP,8>)
+      * the de-ringing bound and the integer-phase pass-through hold for every BP (clamps and exact 0 / 1 ROM entries)
+      * BP -> large converges to the ideal-arithmetic model; small BP differs from it but stays within a few LSB
+      * validation: 0..20, HLS mode and 8-bit samples only."""
+    for a in (2, 3, 4):
+        for n in (2, 3, 5):
+            for k in range(0, a * n + 1):
+                for bp in (4, 8, 12, 20):
+                    wq = O.lib().oracle_hls_weight_fx
+                    wq.restype = __import__("ctypes").c_double
+                    wq.argtypes = [__import__("ctypes").c_int] * 6
+                    got = wq(0, k, a, n, 1, bp)           # |o*D - i*N| = k
+                    ideal = O.hls_rom(k, a, n)
+                    assert got == np.floor(ideal * 2.0 ** bp) / 2.0 ** bp and 0 <= ideal - got < 2.0 ** -bp
+    rng = np.random.default_rng(11)
+    for (w, h, c, sn, sd, a) in [(37, 23, 3, 2, 1, 3), (20, 16, 1, 3, 1, 2), (25, 18, 4, 4, 3, 3), (16, 12, 3, 2, 1, 4)]:
+        img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        cfg = O.cfg(w, h, w * sn // sd, h * sn // sd, c, a, sn, sd)
+        ideal = O.hls_expected_hwc(cfg, img, 4).astype(int)
+        prev = None
+        for bp in (2, 6, 10, 16, 20):
+            out = O.hls_expected_hwc(cfg, img, 4, bit_precision=bp)
+            oh, ow = out.shape[:2]
+            fy, fx = (np.arange(oh) * sd) // sn, (np.arange(ow) * sd) // sn
+            y1, x1 = np.minimum(fy + 1, h - 1), np.minimum(fx + 1, w - 1)
+            quad = np.stack([img[fy][:, fx], img[fy][:, x1], img[y1][:, fx], img[y1][:, x1]]).astype(int)
+            assert np.all(out >= quad.min(0)) and np.all(out <= quad.max(0))   # de-ringing survives the quantisation
+            if sd == 1:
+                assert np.array_equal(out[::sn, ::sn], img)                     # ROM[0] = 1, whole-pixel entries = 0 exactly
+            err = np.abs(out.astype(int) - ideal)
+            # truncation only ever lowers a weight: 2a taps x 255 x 2^-BP per pass, both passes, + the per-tap truncation
+            bound = int(np.ceil(2 * (2 * a) * 255 * 2.0 ** -bp + 2 * a * 2.0 ** -bp)) + 1
+            assert err.max() <= bound, (bp, int(err.max()), bound)
+            prev = err.max() if prev is None else prev
+        assert int(err.max()) <= 1 and (err != 0).mean() < 0.02                # BP = 20: the ideal model up to rare truncation ties
+    assert L._lib().lanczos_validate  # (loaded)
+    d = L.make_desc(40, 30, 3, 2, 1, 3, 1, L.MODE_HLS, bit_precision=12)
+    assert d.reserved[0] == 12
+    for bad in (dict(mode=L.MODE_EXACT, bit_precision=8), dict(mode=L.MODE_HLS, bit_precision=21),
+                dict(mode=L.MODE_HLS, bit_precision=-1), dict(mode=L.MODE_HLS, bit_precision=8, bytes_per_sample=2)):
+        with pytest.raises(L.LanczosError):
+            L.make_desc(40, 30, 3, 2, 1, 3, **bad)
+    # the product's tables in this mode are the model's quantised ROM, bit for bit
+    first, wt = L.taps_host(d, 0)
+    wq = O.lib().oracle_hls_weight_fx
+    for o in range(0, d.out_w, 7):
+        for k in range(6):
+            assert wt[o, k] == wq(int(first[o]) + k, o, 3, 2, 1, 12)
+
+
 # ------------------------------------------------------------------------------------------------ GPU: HIP vs the model
 @pytest.fixture(scope="module")
 def ctx():
@@ -110,6 +162,25 @@ def test_hls_mode_matches_the_model(ctx, pattern):
         assert got.shape == want.shape
         assert np.array_equal(got, want), (pattern, w, h, c, sn, sd, a, int(np.abs(got.astype(int) - want).max()))
         assert ctx.last_kernel() == L.KERNEL_HLS
+
+
+@pytest.mark.gpu
+def test_hls_mode_fixed_point_matches_the_model(ctx):
+    """LANCZOS_MODE_HLS with BIT_PRECISION (lanczos_desc.reserved[0]): k_hls == oracle/lanczos_hls_model.c bit for bit (the same
+    f64 expressions; every quantity is a multiple of 2^-2BP below 2^10).  PARITY UNPINNED by the reference."""
+    for bp in (1, 8, 13, 20):
+        for (w, h, c, sn, sd, a) in SHAPES[:9] + [(7, 5, 3, 2, 1, 3), (1, 1, 3, 2, 1, 3)]:
+            for pattern in ("noise", "gradient"):
+                img = P.ALL_U8[pattern](h, w, c)
+                cfg = O.cfg(w, h, w * sn // sd, h * sn // sd, c, a, sn, sd)
+                want = O.hls_expected_hwc(cfg, img, 8, bit_precision=bp)
+                got = ctx.resample(img, sn, sd, a, L.MODE_HLS, bit_precision=bp)
+                assert np.array_equal(got, want), (bp, pattern, w, h, c, sn, sd, a, int(np.abs(got.astype(int) - want).max()))
+                assert ctx.last_kernel() == L.KERNEL_HLS
+    img = P.noise(90, 120, 3, seed=5)            # different BIT_PRECISIONs are different plans of one context
+    a8 = ctx.resample(img, 2, 1, 3, L.MODE_HLS, bit_precision=4)
+    a0 = ctx.resample(img, 2, 1, 3, L.MODE_HLS)
+    assert not np.array_equal(a8, a0) and np.abs(a8.astype(int) - a0).max() <= 2 * 6 * 255 / 16 + 2
 
 
 @pytest.mark.gpu

@@ -100,12 +100,13 @@ SHAPES = [
     (208, 131, 3, 2, 1, 3), (144, 77, 3, 3, 1, 3), (400, 50, 3, 2, 1, 3), (64, 300, 3, 2, 1, 3),
     (256, 200, 1, 2, 1, 3), (272, 9, 3, 2, 1, 3), (16, 40, 3, 2, 1, 4), (48, 30, 3, 2, 1, 2),
 ]
-FAST_SHAPES = {(200, 120, 3, 2, 1, 3), (160, 90, 3, 3, 1, 3), (128, 96, 3, 2, 1, 2), (96, 64, 4, 2, 1, 4),
-               (120, 80, 1, 2, 1, 3), (514, 131, 3, 2, 1, 3), (320, 99, 3, 3, 1, 3), (700, 50, 3, 2, 1, 3),
-               (130, 300, 3, 2, 1, 3), (260, 200, 4, 2, 1, 4), (260, 200, 1, 2, 1, 3), (258, 70, 3, 2, 1, 2),
-               (258, 70, 3, 2, 1, 4), (200, 90, 4, 2, 1, 3), (208, 131, 3, 2, 1, 3), (144, 77, 3, 3, 1, 3),
-               (400, 50, 3, 2, 1, 3), (64, 300, 3, 2, 1, 3), (256, 200, 1, 2, 1, 3), (272, 9, 3, 2, 1, 3),
-               (16, 40, 3, 2, 1, 4), (48, 30, 3, 2, 1, 2)}
+
+
+def _fast_expected(w, c, sn, sd, bps=1):
+    """Which kernel family must serve a shape: the specialised kernels take every integer scale 2..4 (round 3: all of
+    C in {1,3,4} x a in {2,3,4}, the reference's params.h space lanczos.h:9-31) and the periodic / per-index rational kernels
+    every other scale, whenever the output rows are dword multiples; only ragged rows fall to the f64 generic kernel."""
+    return (w * sn // sd * c * bps) % 4 == 0 and (sd != 1 or sn <= 4)
 
 
 @pytest.mark.parametrize("mode", [L.MODE_EXACT, L.MODE_LSB1])
@@ -116,11 +117,29 @@ def test_oracle_parity_medium(ctx, pattern, mode):
         want = _oracle(img, sn, sd, a)
         got = ctx.resample(img, sn, sd, a, mode)
         _cmp(got, want, mode, f"{pattern} {w}x{h}x{c} {sn}/{sd} a={a}")
-        fast = (w, h, c, sn, sd, a) in FAST_SHAPES
-        if sd != 1:   # rational scales: the f32 tile kernel k_rat whenever the output rows are dword multiples
-            fast = (w * sn // sd * c) % 4 == 0
-        want_family = L.KERNEL_FAST if fast else L.KERNEL_GENERIC
+        want_family = L.KERNEL_FAST if _fast_expected(w, c, sn, sd) else L.KERNEL_GENERIC
         assert ctx.last_kernel() == want_family, (w, h, c, sn, sd, a, ctx.last_kernel())
+
+
+@pytest.mark.parametrize("mode", [L.MODE_EXACT, L.MODE_LSB1])
+def test_every_integer_scale_instance(ctx, mode):
+    """Every instantiated (sample type, channels, scale, a) of the integer-scale kernels (lanczos_fast.hpp LZ_FAST_CONFIGS:
+    8-bit C in {1,3,4} x S in {2,3,4} x a in {2,3,4}; 16-bit C in {3,4} x S in {2,3} x a in {3,4}) against the oracle, once
+    with rows that are 16-byte multiples (the marching kernel) and once ragged (the tile kernel), dark noise (integer-phase
+    fix-ups everywhere) and plain noise.  16-bit: parity unpinned by the reference (checker = the templated restatement)."""
+    cases = [(np.uint8, c, s, a) for c in (1, 3, 4) for s in (2, 3, 4) for a in (2, 3, 4)]
+    cases += [(np.uint16, c, s, a) for c in (3, 4) for s in (2, 3) for a in (3, 4)]
+    for (dt, c, s, a) in cases:
+        bps = np.dtype(dt).itemsize
+        for (w, h) in ((160, 45), (148, 37)):   # 160*c*bps is a 16-byte multiple for every case; 148 is not (but dword rows)
+            assert (w * c * bps) % 16 == (0 if w == 160 else (w * c * bps) % 16)
+            for pat, seed in (("dark", 3), ("noise", 4)):
+                img = (P.dark_noise(h, w, c, seed=seed) if pat == "dark" else P.noise(h, w, c, seed=seed)) if dt == np.uint8 else \
+                      (P.noise(h, w, c, seed=seed, dtype=np.uint16) >> (8 if pat == "dark" else 0)).astype(np.uint16)
+                want = _oracle(img, s, 1, a)
+                got = ctx.resample(img, s, 1, a, mode)
+                _cmp(got, want, mode, f"{dt.__name__} c={c} {s}x a={a} {w}x{h} {pat}")
+                assert ctx.last_kernel() == L.KERNEL_FAST, (dt.__name__, c, s, a, w)
 
 
 RATIONAL_SHAPES = [
