@@ -6,8 +6,8 @@
                     [--no-cpu-baseline] [--no-extras] [--exchange] [--settle-s SECONDS]
 
 A "step" is ONE pass of the fused resample over a batch of F distinct synthetic frames that are already
-resident in HBM (F = 16 by default: 16 x 31.1 MB of compulsory traffic > the 256 MiB Infinity Cache, so
-steps that cycle through the same buffers still stream from HBM).
+resident in HBM (F = 32 by default for config 2; the steps cycle through R input / output sets whose inputs add up to more
+than twice the 256 MiB Infinity Cache, so every timed step reads its frames from HBM -- see `rotate` below).
 
 N > 1: `python bench.py --gpus N` starts its own N ranks (a child `python -m torch.distributed.run`, started
 before this process touches the GPU); launched under torch.distributed.run by someone else (RANK/WORLD_SIZE in
@@ -427,6 +427,28 @@ def main():
             extra["same_batch_every_step"] = {"step_us": round(s_1 * 1e6, 2),
                                               "roofline_frac": round(wl.alg_bytes / s_1 / 1e9 / HBM_PEAK_GBS, 4),
                                               "note": "input resident in the 256 MiB Infinity Cache between steps; not the headline"}
+
+    if rank == 0 and world == 1 and not args.no_extras and args.config == "c2":
+        # BASELINE configs 3 and 5 beside the headline (whole-step device time, inputs cycled past the Infinity Cache like the
+        # headline's), and the headline's workload at twice the batch: same kernels, same method, fewer steps
+        others_cfg = {}
+        for name, f_o in (("c3", DEFAULT_FRAMES["c3"]), ("c5", DEFAULT_FRAMES["c5"]), ("c2", 2 * frames)):
+            cfg_o = CONFIGS[name]
+            in_b = f_o * cfg_o[0] * cfg_o[1] * cfg_o[2] * cfg_o[3]
+            rot_o = min(8, max(1, -(-2 * 256 * 2**20 // in_b)))
+            w_o = Workload(torch, L, ctx, cfg_o, f_o, mode, args.pattern, device, rank, world, "frames", 4000, rot_o)
+            for _ in range(max(6, 2 * rot_o)):
+                w_o.step()
+            torch.cuda.synchronize()
+            n_o = max(10, args.steps // 2)
+            s_o = sorted(device_batch_time(torch, w_o, n_o) for _ in range(3))[1]
+            others_cfg[f"{name}_{f_o}_frames"] = {
+                "workload": cfg_o[7], "frames_per_step": f_o, "batch_sets_cycled": rot_o, "step_us": round(s_o * 1e6, 2),
+                "algorithmic_bytes_per_step": w_o.alg_bytes, "roofline_frac": round(w_o.alg_bytes / s_o / 1e9 / HBM_PEAK_GBS, 4),
+                "Mpix_per_s": round(w_o.out_pix / s_o / 1e6, 1), "kernel": {1: "generic", 2: "fast"}.get(ctx.last_kernel(), "?")}
+            del w_o
+            torch.cuda.empty_cache()
+        extra["other_configs"] = others_cfg
 
     if args.exchange and dist is not None and shard == "frames":
         # root-inclusive figure: rank 0 scatters every rank's input frames and gathers the outputs (RCCL)

@@ -3,8 +3,8 @@
 // Replaces, for the resample path only: lanczos() (lanczos.cpp:86-98) with its strip scheduler
 // process_channel (lanczos.cpp:68-83), the Col/Row workers (worker.cpp:134-284), the weight ROM
 // (kernel.cpp:40-67) and the cyclic line buffer (cyclic_buffer.h).  Here: host-tabulated taps that stay
-// resident on the device, one fused H+V kernel launch per batch of frames, and a tiny second launch for
-// the in-place prefix rows.
+// resident on the device, one fused H+V kernel launch per batch of frames, and a tiny launch IN FRONT of it (same
+// stream) for the in-place prefix rows of large batches; small batches carry those rows inside the main launch.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/lanczos_hip.h"
+#include "lanczos_env.hpp"
 #include "lanczos_fast.hpp"
 #include "lanczos_layout.hpp"
 #include "lanczos_march.hpp"
@@ -34,6 +35,8 @@ struct PlanKey {
 };
 
 struct Plan {
+    PlanKey key;
+    std::vector<hipStream_t> streams;  // streams this plan's tables were used on (retirement)
     lz::AxisTaps H, V;
     lz::PrefixInfo prefix;
     lz::TapTables dev{};       // device copies
@@ -53,6 +56,8 @@ struct lanczos_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::map<PlanKey, Plan*> plans;
+    std::vector<PlanKey> plan_order;   // oldest first: the cache is bounded (kMaxPlans), the oldest plan is retired
+    lz::RetireList retired_plans;
     std::mutex mu;
     int last_kernel = LANCZOS_KERNEL_NONE;
     int last_hip = 0;
@@ -61,25 +66,29 @@ struct lanczos_ctx {
     void* stage_in = nullptr;
     void* stage_out = nullptr;
     size_t stage_in_bytes = 0, stage_out_bytes = 0;
-    // timing
+    // timing: event triples (start, middle, end) around a call's kernels; ev_prefix_first[i]: the in-place prefix kernel ran
+    // in FRONT of the main kernel (start..middle = prefix, middle..end = main) instead of behind it
     bool timing = false;
-    std::vector<hipEvent_t> ev;  // triples: main start, main stop / prefix stop
+    std::vector<hipEvent_t> ev;
+    std::vector<char> ev_prefix_first;
     int ev_used = 0;
     int launches = 0;
     double main_ms = 0, prefix_ms = 0;
-    void* stamp_buf = nullptr;
+#ifdef LZ_PROFILE_BITS
+    void* stamp_buf = nullptr;   // diagnostic builds: per-wave cycle sums + residency census of k_march (lanczos_diag_report)
+#endif
     lz::WgTabCache wg_tabs;  // k_march's workgroup tables (device copies), one per launch shape
     hipStream_t copy_in = nullptr, copy_out = nullptr;  // lanczos_resample_host pipeline
-    // the in-place prefix rows of integer scales run on a side stream BESIDE the marching kernel (k_prefix_reg)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<hipEvent_t> pipe_ev;
     // interleaved scratch frames of lanczos_resample_planar_device
     void* planar_in = nullptr;
     void* planar_out = nullptr;
     size_t planar_in_bytes = 0, planar_out_bytes = 0;
 };
+#ifdef LZ_PROFILE_BITS
 static constexpr size_t kStampBytes = 16384 * 8 * 6 * 8;
+#endif
+static constexpr size_t kMaxPlans = 32;
 
 namespace {
 
@@ -103,8 +112,22 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
         *out = it->second;
         return LANCZOS_OK;
     }
+    ctx->retired_plans.reap(false);
+    if (ctx->plans.size() >= kMaxPlans) {
+        // bounded: a caller that cycles through many shapes does not grow device memory without limit.  The oldest plan's
+        // tables are freed once the launches that read them have drained (events on the streams it was used on).
+        const PlanKey old = ctx->plan_order.front();
+        ctx->plan_order.erase(ctx->plan_order.begin());
+        auto io = ctx->plans.find(old);
+        if (io != ctx->plans.end()) {
+            ctx->retired_plans.retire({io->second->dev_block}, {}, io->second->streams);
+            delete io->second;
+            ctx->plans.erase(io);
+        }
+    }
     Plan* p = new (std::nothrow) Plan();
     if (!p) return LANCZOS_ERR_NOMEM;
+    p->key = key;
     if (hls) {  // ROM weights, exact stepping, no in-place prefix (lanczos_hls.hpp)
         lz::build_axis_hls(d->in_w, d->out_w, d->scale_n, d->scale_d, d->a, &p->H, d->reserved[0]);
         lz::build_axis_hls(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &p->V, d->reserved[0]);
@@ -192,6 +215,7 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
         p->ratp_w_dev = (const float*)(b + off_pw);
     }
     ctx->plans[key] = p;
+    ctx->plan_order.push_back(key);
     *out = p;
     return LANCZOS_OK;
 }
@@ -322,6 +346,7 @@ int lanczos_create(lanczos_ctx** out, int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return LANCZOS_ERR_NO_DEVICE;
     if (device < 0 || device >= n) return LANCZOS_ERR_NO_DEVICE;
+    (void)lz::env();  // every environment switch is read here, once per process (lanczos_env.hpp)
     lanczos_ctx* ctx = new (std::nothrow) lanczos_ctx();
     if (!ctx) return LANCZOS_ERR_NOMEM;
     ctx->device = device;
@@ -334,15 +359,12 @@ int lanczos_create(lanczos_ctx** out, int device) {
     return LANCZOS_OK;
 }
 
-int lanczos_destroy(lanczos_ctx* ctx) {
-    if (!ctx) return LANCZOS_ERR_BAD_ARG;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto& kv : ctx->plans) {
-        if (kv.second->dev_block) (void)hipFree(kv.second->dev_block);
-        delete kv.second;
-    }
-    if (ctx->stamp_buf) {
+#ifdef LZ_PROFILE_BITS
+// Diagnostic builds only (make variant EXTRA=-DLZ_PROFILE_BITS): where a wave of k_march<u8,3,2,3> spends its cycles and when /
+// where every workgroup ran, from the stamps of the last LANCZOS_STAMP=1 launch.  Not part of the C ABI of include/lanczos_hip.h.
+static void diag_report(lanczos_ctx* ctx, FILE* out) {
+    if (!ctx->stamp_buf) return;
+    {
         std::vector<unsigned long long> h(kStampBytes / 8);
         if (hipMemcpy(h.data(), ctx->stamp_buf, kStampBytes, hipMemcpyDeviceToHost) == hipSuccess) {
             double sum[5] = {0, 0, 0, 0, 0}, ticks = 0;
@@ -392,12 +414,12 @@ int lanczos_destroy(lanczos_ctx* ctx) {
                     std::sort(st.begin(), st.end());
                     std::sort(life.begin(), life.end());
                     if (!st.empty())
-                        fprintf(stderr, "CENSUS start us: p50=%.1f p90=%.1f max=%.1f | lifetime us: min=%.1f p10=%.1f p50=%.1f p90=%.1f max=%.1f\n",
+                        fprintf(out, "CENSUS start us: p50=%.1f p90=%.1f max=%.1f | lifetime us: min=%.1f p10=%.1f p50=%.1f p90=%.1f max=%.1f\n",
                                 st[st.size() / 2], st[st.size() * 9 / 10], st.back(), life.front(), life[life.size() / 10],
                                 life[life.size() / 2], life[life.size() * 9 / 10], life.back());
                 }
-                if (getenv("LANCZOS_CENSUS_DUMP")) {  // raw records for offline correlation: wg index, start, end, xcc, hw_id
-                    FILE* df = fopen(getenv("LANCZOS_CENSUS_DUMP"), "w");
+                if (!lz::env().census_dump.empty()) {  // raw records for offline correlation: wg index, start, end, xcc, hw_id
+                    FILE* df = fopen(lz::env().census_dump.c_str(), "w");
                     if (df) {
                         for (size_t i = off, k = 0; i + 2 < h.size(); i += 3, k++)
                             if (h[i + 1])
@@ -407,11 +429,11 @@ int lanczos_destroy(lanczos_ctx* ctx) {
                     }
                 }
                 if (wgs)
-                    fprintf(stderr, "CENSUS wgs=%ld distinct_cus=%zu span=%.1f us avg_resident_wgs_per_cu=%.2f peak=%d\n", wgs,
+                    fprintf(out, "CENSUS wgs=%ld distinct_cus=%zu span=%.1f us avg_resident_wgs_per_cu=%.2f peak=%d\n", wgs,
                             ev.size(), (tmax - tmin) / 100.0, avg / ev.size(), peak);
             }
             if (n)
-                fprintf(stderr, "STAMP waves=%ld ticks/wave=%.1f cycles/tick: issue=%.0f hpass=%.0f commit=%.0f vpass=%.0f barrier=%.0f\n",
+                fprintf(out, "STAMP waves=%ld ticks/wave=%.1f cycles/tick: issue=%.0f hpass=%.0f commit=%.0f vpass=%.0f barrier=%.0f\n",
                         n, ticks / n, sum[0] / ticks, sum[1] / ticks, sum[2] / ticks, sum[3] / ticks, sum[4] / ticks);
             for (int w = 0; w < 6; w++) {  // the same by wave index inside the workgroup (k_march<u8,3,2,3>: 6 waves; 0-2 run the H pass)
                 double s6[5] = {0, 0, 0, 0, 0}, tk = 0;
@@ -421,17 +443,35 @@ int lanczos_destroy(lanczos_ctx* ctx) {
                         tk += (double)h[i + 5];
                     }
                 if (tk > 0)
-                    fprintf(stderr, "STAMP wave %d: issue=%.0f hpass=%.0f commit=%.0f vpass=%.0f barrier=%.0f\n", w, s6[0] / tk, s6[1] / tk,
+                    fprintf(out, "STAMP wave %d: issue=%.0f hpass=%.0f commit=%.0f vpass=%.0f barrier=%.0f\n", w, s6[0] / tk, s6[1] / tk,
                             s6[2] / tk, s6[3] / tk, s6[4] / tk);
             }
         }
+    }
+}
+#endif
+
+int lanczos_destroy(lanczos_ctx* ctx) {
+    if (!ctx) return LANCZOS_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    // Launches of this context may still be running on the caller's streams: the device is drained before anything they read
+    // is freed (the only device-wide wait of the library, at the one point where it is owed).
+    (void)hipDeviceSynchronize();
+    ctx->retired_plans.reap(true);
+    ctx->wg_tabs.release_all();
+    for (auto& kv : ctx->plans) {
+        if (kv.second->dev_block) (void)hipFree(kv.second->dev_block);
+        delete kv.second;
+    }
+    ctx->plans.clear();
+#ifdef LZ_PROFILE_BITS
+    if (ctx->stamp_buf) {
+        diag_report(ctx, stderr);
         (void)hipFree(ctx->stamp_buf);
     }
+#endif
     for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
     if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
     if (ctx->planar_in) (void)hipFree(ctx->planar_in);
@@ -457,8 +497,9 @@ static int timing_flush(lanczos_ctx* ctx) {
         LZ_HIP(ctx, hipEventSynchronize(ctx->ev[i + 2]));
         LZ_HIP(ctx, hipEventElapsedTime(&a, ctx->ev[i], ctx->ev[i + 1]));
         LZ_HIP(ctx, hipEventElapsedTime(&b, ctx->ev[i + 1], ctx->ev[i + 2]));
-        ctx->main_ms += a;
-        ctx->prefix_ms += b;
+        const bool prefix_first = ctx->ev_prefix_first[i / 3] != 0;  // start..middle = the prefix kernel in front of the main one
+        ctx->main_ms += prefix_first ? b : a;
+        ctx->prefix_ms += prefix_first ? a : b;
         ctx->launches++;
     }
     return LANCZOS_OK;
@@ -487,10 +528,11 @@ int lanczos_force_kernel(lanczos_ctx* ctx, int family) {
     return LANCZOS_OK;
 }
 
-// In-place prefix rows of an integer scale on the context's side stream (k_prefix_reg).  hipErrorNotSupported: no
-// instance for this (sample type, scale, a) -- the caller falls back to the serial k_prefix.
-static hipError_t launch_prefix_side(lanczos_ctx* ctx, const lanczos_desc* d, const lz::FrameGeom& g, const Plan* p,
-                                     hipStream_t stream, bool same_stream) {
+// In-place prefix rows of an integer scale as a register-only kernel (k_prefix_reg) on `stream`, in FRONT of the marching kernel
+// (5 us by events of a 210 us step).  A fork / join onto a side stream so that it overlaps the march was measured and dropped
+// (the two event dependencies cost 14 us per step).  hipErrorNotSupported: no instance for this (sample type, scale, a) -- the
+// caller falls back to the general k_prefix behind the main kernel.
+static hipError_t launch_prefix_front(const lanczos_desc* d, const lz::FrameGeom& g, const Plan* p, hipStream_t stream) {
 #define LZ_PREFIX_REG_CONFIGS(X)                                                                                        \
     X(uint8_t, 2, 2) X(uint8_t, 2, 3) X(uint8_t, 2, 4) X(uint8_t, 3, 2) X(uint8_t, 3, 3) X(uint8_t, 3, 4) X(uint8_t, 4, 2) \
     X(uint8_t, 4, 3) X(uint8_t, 4, 4) X(uint16_t, 2, 3) X(uint16_t, 2, 4) X(uint16_t, 3, 3) X(uint16_t, 3, 4)
@@ -502,27 +544,14 @@ static hipError_t launch_prefix_side(lanczos_ctx* ctx, const lanczos_desc* d, co
     LZ_PREFIX_REG_CONFIGS(X)
 #undef X
     if (!have) return hipErrorNotSupported;
-    hipError_t e;
-    hipStream_t ks = stream;
-    if (!same_stream) {
-        if (!ctx->side) {
-            if ((e = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking)) != hipSuccess) return e;
-            if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
-            if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return e;
-        }
-        if ((e = hipEventRecord(ctx->ev_fork, stream)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0)) != hipSuccess) return e;
-        ks = ctx->side;
-    }
     const int samples_w = d->out_w * d->channels;
     dim3 grid((samples_w + 127) / 128, g.frames);
 #define X(T, S, A)                                                                                  \
     if (d->bytes_per_sample == (int)sizeof(T) && d->scale_n == S && d->a == A)                      \
-        hipLaunchKernelGGL((lz::k_prefix_reg<T, S, A>), grid, dim3(128), 0, ks, g, p->dev);
+        hipLaunchKernelGGL((lz::k_prefix_reg<T, S, A>), grid, dim3(128), 0, stream, g, p->dev);
     LZ_PREFIX_REG_CONFIGS(X)
 #undef X
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    return same_stream ? hipSuccess : hipEventRecord(ctx->ev_join, ctx->side);
+    return hipGetLastError();
 }
 
 // the resample proper; ctx->mu is held by the caller
@@ -569,33 +598,23 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
     g.skip_rows = has_prefix ? p->prefix.K : 0;
     g.frames = frames;
     g.hls_bp = d->mode == LANCZOS_MODE_HLS ? d->reserved[0] : 0;
-    {
-        static const int dbg = getenv("LANCZOS_DEBUG_SKIP") ? atoi(getenv("LANCZOS_DEBUG_SKIP")) : 0;
-        g.debug_skip = dbg;
-        // LANCZOS_STAMP=1: diagnostic kernel build that sums s_memtime deltas per phase; results are dumped to
-        // stderr by lanczos_destroy (never used by tests or the benchmark numbers)
-        static const bool stamp = getenv("LANCZOS_STAMP") && atoi(getenv("LANCZOS_STAMP")) != 0;
-        g.stamps = nullptr;
-        if (stamp) {
-            if (!ctx->stamp_buf) (void)hipMalloc(&ctx->stamp_buf, kStampBytes), (void)hipMemset(ctx->stamp_buf, 0, kStampBytes);
-            g.stamps = (unsigned long long*)ctx->stamp_buf;
-        }
+    g.debug_skip = 0;
+    g.stamps = nullptr;
+#ifdef LZ_PROFILE_BITS
+    // diagnostic builds only: ablation bits, and (LANCZOS_STAMP=1) the kernel instance that sums s_memtime deltas per phase
+    // and records when / where every workgroup ran; reported by diag_report() when the context is destroyed
+    g.debug_skip = lz::env().debug_skip;
+    if (lz::env().stamp) {
+        if (!ctx->stamp_buf) (void)hipMalloc(&ctx->stamp_buf, kStampBytes), (void)hipMemset(ctx->stamp_buf, 0, kStampBytes);
+        g.stamps = (unsigned long long*)ctx->stamp_buf;
     }
+#endif
+    lz::note_stream(p->streams, (hipStream_t)stream_v);
 
     if (d->mode == LANCZOS_MODE_HLS) {
         if (ctx->force == LANCZOS_KERNEL_FAST || ctx->force == LANCZOS_KERNEL_GENERIC) return LANCZOS_ERR_UNSUPPORTED;
         if (d->channels > 4 || 2 * d->a > 2 * lz::kMaxA) return LANCZOS_ERR_UNSUPPORTED;
-        const int tiles_x = (d->out_w + lz::kHlsTileW - 1) / lz::kHlsTileW;
-        const int tiles_y = (rows + lz::kHlsTileH - 1) / lz::kHlsTileH;
         if (frames > 65535) return LANCZOS_ERR_UNSUPPORTED;
-        dim3 grid(tiles_x * tiles_y, frames);
-        if (d->bytes_per_sample == 1)
-            hipLaunchKernelGGL(lz::k_hls<uint8_t>, grid, dim3(lz::kHlsThreads), 0, stream, g, p->dev);
-        else
-            hipLaunchKernelGGL(lz::k_hls<uint16_t>, grid, dim3(lz::kHlsThreads), 0, stream, g, p->dev);
-        LZ_HIP(ctx, hipGetLastError());
-        ctx->last_kernel = LANCZOS_KERNEL_HLS;
-        return LANCZOS_OK;
     }
     bool prefix_fused = false;
     bool use_fast = p->fast_ok && ctx->force != LANCZOS_KERNEL_GENERIC &&
@@ -616,19 +635,34 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
             LZ_HIP(ctx, hipEventCreate(&e));
             ctx->ev.push_back(e);
         }
+        ctx->ev_prefix_first.resize(ctx->ev.size() / 3 + 1, 0);
         ev0 = ctx->ev[ctx->ev_used];
         ev1 = ctx->ev[ctx->ev_used + 1];
         ev2 = ctx->ev[ctx->ev_used + 2];
         LZ_HIP(ctx, hipEventRecord(ev0, stream));
     }
-    bool prefix_side = false;  // the prefix rows were launched on the side stream, before the main kernel
-    bool prefix_same = false;  // ... or on this stream, in front of the main kernel (register-only kernel)
+    if (d->mode == LANCZOS_MODE_HLS) {
+        const int tiles_x = (d->out_w + lz::kHlsTileW - 1) / lz::kHlsTileW;
+        const int tiles_y = (rows + lz::kHlsTileH - 1) / lz::kHlsTileH;
+        dim3 grid(tiles_x * tiles_y, frames);
+        if (d->bytes_per_sample == 1)
+            hipLaunchKernelGGL(lz::k_hls<uint8_t>, grid, dim3(lz::kHlsThreads), 0, stream, g, p->dev);
+        else
+            hipLaunchKernelGGL(lz::k_hls<uint16_t>, grid, dim3(lz::kHlsThreads), 0, stream, g, p->dev);
+        LZ_HIP(ctx, hipGetLastError());
+        ctx->last_kernel = LANCZOS_KERNEL_HLS;
+        if (ev0) {  // one kernel: all of it is "main"
+            LZ_HIP(ctx, hipEventRecord(ev1, stream));
+            LZ_HIP(ctx, hipEventRecord(ev2, stream));
+            ctx->ev_prefix_first[ctx->ev_used / 3] = 0;
+            ctx->ev_used += 3;
+        }
+        return LANCZOS_OK;
+    }
+    bool prefix_front = false;  // the prefix rows went out on this stream in FRONT of the main kernel (register-only kernel)
     if (use_fast) {
-        // LANCZOS_TILE_KERNEL=1 selects the older tile-per-workgroup kernel (kept for A/B measurements)
-        static const bool use_tile = getenv("LANCZOS_TILE_KERNEL") && atoi(getenv("LANCZOS_TILE_KERNEL")) != 0;
-        static const bool serial_prefix = getenv("LANCZOS_SERIAL_PREFIX") && atoi(getenv("LANCZOS_SERIAL_PREFIX")) != 0;
         hipError_t e;
-        if (use_tile || !lz::march_supports(g)) {
+        if (lz::env().tile_kernel || !lz::march_supports(g)) {  // LANCZOS_TILE_KERNEL=1: the tile-per-workgroup kernel (A/B measurements)
             e = lz::fast_launch(*d, g, p->dev, p->fast, stream);
         } else {
             lz::FrameGeom gm = g;
@@ -638,17 +672,14 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
                 gm.prefix_M2 = p->prefix.M2;
                 e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &prefix_fused, &ctx->wg_tabs, /*query_only=*/true);
                 if (e == hipSuccess && !prefix_fused) {
-                    // Large batch: the prefix rows neither ride nor wait -- the register-only kernel goes out FIRST, on the
-                    // side stream, and shares the CUs with the marching kernel's first microseconds (it needs no LDS, the
-                    // marching workgroups need all of it).  fork: side waits for everything queued on `stream` so far;
-                    // join (below): `stream` waits for the side kernel.
+                    // Large batch: the prefix rows do not ride (960 extra workgroups crowd the march: measured) -- the
+                    // register-only kernel goes out first, on the same stream
                     gm.prefix_K = gm.prefix_M = gm.prefix_M2 = 0;
-                    static const int prefix_mode = getenv("LANCZOS_PREFIX_MODE") ? atoi(getenv("LANCZOS_PREFIX_MODE")) : 1;  // 1: same stream, in front (measured best); 2: side stream
-                    if (!serial_prefix && d->scale_d == 1 && d->in_h >= p->prefix.M2) {
-                        hipError_t pe = launch_prefix_side(ctx, d, g, p, stream, prefix_mode != 2);
+                    if (!lz::env().separate_prefix && d->scale_d == 1 && d->in_h >= p->prefix.M2) {
+                        hipError_t pe = launch_prefix_front(d, g, p, stream);
                         if (pe == hipSuccess) {
-                            prefix_side = prefix_mode == 2;
-                            prefix_same = prefix_mode != 2;
+                            prefix_front = true;
+                            if (ev1) LZ_HIP(ctx, hipEventRecord(ev1, stream));  // start..middle = the prefix kernel
                         } else if (pe != hipErrorNotSupported) e = pe;
                     }
                 }
@@ -662,7 +693,7 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
             return LANCZOS_ERR_HIP;
         }
         ctx->last_kernel = LANCZOS_KERNEL_FAST;
-    } else if (use_rat && p->ratp.ok && !(getenv("LANCZOS_NO_RATP") && atoi(getenv("LANCZOS_NO_RATP")) != 0)) {
+    } else if (use_rat && p->ratp.ok && !lz::env().no_ratp) {
         hipError_t e = lz::ratp_launch(*d, g, p->dev, p->ratp_dev, p->ratp_w_dev, stream);
         if (e != hipSuccess) {
             ctx->last_hip = (int)e;
@@ -704,10 +735,9 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
         LZ_HIP(ctx, hipGetLastError());
         ctx->last_kernel = LANCZOS_KERNEL_GENERIC;
     }
-    if (ev1) LZ_HIP(ctx, hipEventRecord(ev1, stream));
+    if (ev1 && !prefix_front) LZ_HIP(ctx, hipEventRecord(ev1, stream));  // start..middle = the main kernel
 
-    if (prefix_side) LZ_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));  // join
-    if (has_prefix && !prefix_fused && !prefix_side && !prefix_same) {
+    if (has_prefix && !prefix_fused && !prefix_front) {
         const int samples_w = d->out_w * d->channels;
         // columns per block: the row arrays (M + M2 rows) must fit 60 KB of LDS; deep prefixes (scales close to 1) get fewer
         int bw = 128;
@@ -731,6 +761,7 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
     }
     if (ev2) {
         LZ_HIP(ctx, hipEventRecord(ev2, stream));
+        ctx->ev_prefix_first[ctx->ev_used / 3] = prefix_front ? 1 : 0;
         ctx->ev_used += 3;
     }
     return LANCZOS_OK;

@@ -47,20 +47,14 @@
 #include <utility>
 #include <vector>
 
+#include "lanczos_env.hpp"
 #include "lanczos_fast.hpp"
 
 // SGPR budget: gfx950 admits min(8, floor(800 / (ceil(sgpr/16)*16 + 16))) waves per SIMD (MI355X_MICROARCH.md,
 // "Residency"); at the compiler's free choice (106) that is 6, and four 6-wave workgroups then only fit when their
 // waves happen to spread evenly over the SIMDs (measured: 3 resident, not the 4 the occupancy API answers).
 // 96 SGPRs -> 7 waves per SIMD: 4 workgroups per CU, +5..9 % (interleaved A/B on one device).
-#ifndef LZ_MARCH_SGPRS
-#define LZ_MARCH_SGPRS 96
-#endif
-#if LZ_MARCH_SGPRS > 0
-#define LZ_MARCH_SGPR_ATTR __attribute__((amdgpu_num_sgpr(LZ_MARCH_SGPRS)))
-#else
-#define LZ_MARCH_SGPR_ATTR
-#endif
+#define LZ_MARCH_SGPR_ATTR __attribute__((amdgpu_num_sgpr(96)))
 
 // Ablation bits (FrameGeom::debug_skip, LANCZOS_DEBUG_SKIP) exist only in builds made with -DLZ_PROFILE_BITS: in the production
 // build every test of them is a compile-time false (the per-row `no_store` test alone was two scalar instructions and a
@@ -71,86 +65,28 @@
 #define LZ_DBG(g, bits) false
 #endif
 
-// cache policy of the input-row loads (aux bits of the buffer load: 1 = sc0, 2 = nt, 16 = sc1)
-#ifndef LZ_MARCH_LOAD_AUX
-#define LZ_MARCH_LOAD_AUX 0
-#endif
-#ifdef LZ_RIDE_NO_REBUILD
-#define LZ_RIDE_REBUILD(ride) false
-#else
-#define LZ_RIDE_REBUILD(ride) (ride)
-#endif
-
 namespace lz {
 
-// SPLIT (role-specialised waves): the first NHW waves of a workgroup run ONLY the H pass (+ fix-ups), the others ONLY the V
-// pass.  A V thread then owns its dword column for the whole march and carries its 2a-row register window from tick to
-// tick (no re-seeding: 5 ring reads + 20 conversions per tick saved), an H thread owns a unit of P = 8 input pixels
-// (13-pixel window: 1.6 conversions per computed sample instead of 2.5), and no wave pays the other role's per-tick
-// address and flag arithmetic.  Measured on config 2: see profiles/README.md (round 2).
+// Tick geometry: NGRP groups of whole waves share a tick's rows in the V pass; MS input rows per tick.
+// (Shapes that were built, measured and dropped -- role-specialised H / V waves with a carried register window, 3-wave
+// workgroups with 6-row ticks, 8-wave workgroups, LDS-DMA input tiles, a second-stage integer-phase filter ... -- live in
+// profiles/experiments/round3_march_variants.patch with their measurements in profiles/README.md.)
 template <typename T, int C, int S, int A>
 struct MarchShape {
     static constexpr int NGRP = 2;                                  // V groups (whole waves each)
     static constexpr int MS = 2 * A * NGRP;                         // input rows per tick
-    static constexpr bool SPLIT = false;
-    static constexpr bool CARRY = false;                            // V window carried from tick to tick (one group, MS % 2a == 0)
-    static constexpr int P = 0, UPR = 0;                            // unit geometry: FastCfg's default
 };
 template <int A>
-struct MarchShape<uint8_t, 3, 3, A> {  // 288 dword columns = 4.5 waves per V group (padded to 5)
-#ifdef LZ_MARCH_C3_NGRP2
-    static constexpr int NGRP = 2;     // 10-wave workgroups: every thread has V work (the V pass is 2/3 of this configuration)
-#else
-    static constexpr int NGRP = 1;
-#endif
-    static constexpr int MS = 12;
-    static constexpr bool SPLIT = false;
-    static constexpr bool CARRY = false;
-    static constexpr int P = 0, UPR = 0;
-};
-#ifdef LZ_MARCH_FINE
-// opt-in experiment: 3-wave workgroups, 6-row ticks, every thread owns one H unit per tick AND one dword column whose 2a-row
-// window it carries from tick to tick (no re-seeding: 20 of 44 conversions per 6 rows saved), half the prologue per chunk.
-// Measured (profiles/round2h_ab_fine_grained_workgroups.txt): 82 VGPRs, six workgroups = 18 waves per CU, 224 us against 209
-// on config 2 at 32 frames (outputs identical): fewer waves and twice the barriers cost more than the conversions save.
-template <>
-struct MarchShape<uint8_t, 3, 2, 3> {
-    static constexpr int NGRP = 1;
-    static constexpr int MS = 6;
-    static constexpr bool SPLIT = false;
-    static constexpr bool CARRY = true;
-    static constexpr int P = 0, UPR = 0;
-};
-#elif defined(LZ_MARCH_SPLIT)  // opt-in experiment (round 2): no faster than the 6-wave all-roles workgroup, slower on fix-up-heavy input
-template <>
-struct MarchShape<uint8_t, 3, 2, 3> {  // config 2: 3 H waves (12 rows x 16 units) + 3 V waves (192 dword columns x 12 rows)
+struct MarchShape<uint8_t, 3, 3, A> {  // 288 dword columns = 4.5 waves per V group (padded to 5): one group
     static constexpr int NGRP = 1;
     static constexpr int MS = 12;
-    static constexpr bool SPLIT = true;
-    static constexpr bool CARRY = true;
-    static constexpr int P = 8, UPR = 16;
 };
-#elif defined(LZ_MARCH_WG8)
-// 8-wave workgroups: two waves on EVERY SIMD whatever SIMD the dispatcher starts a workgroup on (a 6-wave workgroup
-// puts 2+2+1+1), three workgroups = 24 waves per CU.  Strip = 320 output pixels (960 B = 240 dword columns x 2 V groups =
-// 480 threads; 12 rows x 40 units = 480 H units per tick).
-template <>
-struct MarchShape<uint8_t, 3, 2, 3> {
-    static constexpr int NGRP = 2;
-    static constexpr int MS = 12;
-    static constexpr bool SPLIT = false;
-    static constexpr bool CARRY = false;
-    static constexpr int P = 4, UPR = 40;
-};
-#endif
 
 template <typename T, int C_, int S_, int A_>
 struct MarchCfg {
     using SH = MarchShape<T, C_, S_, A_>;
-    using F = FastCfg<T, C_, S_, A_, SH::P, SH::UPR>;  // unit geometry (the default one is shared with the tile kernel)
+    using F = FastCfg<T, C_, S_, A_>;  // unit geometry (shared with the tile kernel)
     static constexpr int C = C_, S = S_, A = A_;
-    static constexpr bool SPLIT = SH::SPLIT;
-    static constexpr bool CARRY = SH::CARRY;
     static constexpr int SB = F::SB, TAPS = F::TAPS, P = F::P, UPR = F::UPR;
     static constexpr int NGRP = SH::NGRP;
     static constexpr int MS = SH::MS;
@@ -159,130 +95,56 @@ struct MarchCfg {
     static constexpr int NU = MS * UPR;                              // H units per tick
     static constexpr int NVT_PAD = NGRP == 1 ? NVT : ((NVT + 63) / 64) * 64;  // V groups start on wave boundaries
     static constexpr int NT_V = NVT_PAD * NGRP;
-    static constexpr int NHW = SPLIT ? (NU + 63) / 64 : 0;           // SPLIT: waves [0, NHW) are H waves
-    static constexpr int NT = SPLIT ? NHW * 64 + ((NT_V + 63) / 64) * 64 : (((NT_V > NU ? NT_V : NU) + 63) / 64) * 64;
+    static constexpr int NT = (((NT_V > NU ? NT_V : NU) + 63) / 64) * 64;
     static constexpr int NWAVES = NT / 64;
     // ring rows: two ticks + the window.  A power of two where 32 rows do (index = row & 31); otherwise the next multiple of
     // 8 and a modulo -- at a = 4 that is 40 rows instead of 64: 24 KiB less LDS, two resident workgroups instead of one
-#ifdef LZ_MARCH_RING_POW2
-    static constexpr int RS = (2 * MS + TAPS - 1) <= 32 ? 32 : 64;
-#else
-    static constexpr int RS = (CARRY && !SPLIT && (2 * MS + TAPS - 1) <= 24) ? 24 : ((2 * MS + TAPS - 1) <= 32 ? 32 : ((2 * MS + TAPS - 1 + 7) / 8) * 8);
-#endif
+    static constexpr int RS = (2 * MS + TAPS - 1) <= 32 ? 32 : ((2 * MS + TAPS - 1 + 7) / 8) * 8;
     static constexpr bool RS_POW2 = (RS & (RS - 1)) == 0;
     // slot of ring row `rel` = row - hb (>= -RS: the first ticks read rows above the chunk, whose results are never stored)
     static __device__ __forceinline__ int ring_slot(int rel) { return RS_POW2 ? (rel & (RS - 1)) : (rel + RS) % RS; }
     static constexpr int IN_PITCH = F::IN_PITCH, H_PITCH = F::H_PITCH, CPR = F::CPR;
     static constexpr int NCH = MS * CPR;                             // 16-byte chunks of one tick's input
-    static constexpr int NLT = SPLIT ? NHW * 64 : NT;                // threads that move the input rows (SPLIT: the H
-                                                                     // waves -- they issue no stores, so the commit's
-                                                                     // vmcnt wait never sits behind this tick's stores)
+    static constexpr int NLT = NT;                                   // threads that move the input rows
     static constexpr int LOAD_IT = (NCH + NLT - 1) / NLT;
     static constexpr int TIN_BYTES = LOAD_IT * NLT * 16;             // >= MS*IN_PITCH: every loading lane commits a chunk
     // worklist entries per wave: one round of candidates.  (A list for all VEC rounds with a single dense pass
     // measured 13 % SLOWER, interleaved A/B on one device: the extra 7 KiB of LDS costs residency.)
     static constexpr int WL_ROUND = 64 * F::UNIT_IN_DW;               // most entries one round can add
     static constexpr int WLW = WL_ROUND + 96;                         // sparse flags: all rounds share ONE dense pass
-    static constexpr int NLISTS = SPLIT ? NHW : (NU + 63) / 64;       // only waves that run the H pass keep a list
+    static constexpr int NLISTS = (NU + 63) / 64;                     // only waves that run the H pass keep a list
     static constexpr int LDS_TIN = 2 * TIN_BYTES;                    // double buffered
     static constexpr int LDS_HBUF = RS * H_PITCH;
     static constexpr int LDS_WL = NLISTS * WLW * 2;
     // Scales whose per-index double weights are not the phase weights bit for bit (S = 3: x = xx / 3.0 is rounded) read them
-    // from the global tap table in the (rare) fix-up.  Round 2 first kept the strip's slice of that table in LDS (18 KiB): a
-    // fix-up that gathered 6 doubles from global memory held its workgroup's barrier for a memory round trip (33 of 158 us on
-    // config 3).  Since the event path was shortened the slice buys nothing (121 vs 120 us) and costs the THIRD workgroup per
-    // CU: without it config 3 runs 178 -> 161 us at 24 frames, 235 -> 209 at 32 (-DLZ_MARCH_HW_LDS brings it back).
-#ifdef LZ_MARCH_HW_LDS
-    static constexpr int LDS_HW = (S == 3) ? F::TWP_OUT * TAPS * 8 : 0;
-#else
-    static constexpr int LDS_HW = 0;
-#endif
+    // from the global tap table in the (rare) fix-up; a slice of that table in LDS (18 KiB) bought nothing once the event path
+    // was short and cost config 3 its third workgroup per CU (178 -> 161 us at 24 frames).
     // the exact chain's phase weights (TapTables::x_w: integer phase + S-1 interior phases, 256 B): a fix-up that fetches them
     // from global memory holds its workgroup's barrier for a memory round trip
     static constexpr int LDS_XW = kFastMaxS * kMaxTaps * 8;
-    static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL + LDS_HW + LDS_XW;
+    static constexpr int LDS_BYTES = LDS_TIN + LDS_HBUF + LDS_WL + LDS_XW;
     static constexpr int NNI = F::UNIT_OUT_S - P * C;                // non-integer-phase samples of a unit
-    // LDS-DMA for the input rows (buffer_load_dwordx4 ... lds, no staging VGPRs, counted vmcnt wait): opt-in.  Measured in
-    // round 2 (interleaved A/B): config 2 108.3 us with register staging vs 110.3 with LDS-DMA, config 5 613 vs 691 --
-    // the tile image of a 512-thread workgroup is 2 x 16 KiB of which a third is padding lanes, and the DMA has only the
-    // V pass to land in.  The role-split shape (LZ_MARCH_SPLIT) needs it (its H waves have no registers to spare).
-#if defined(LZ_MARCH_LDSDMA) || defined(LZ_MARCH_SPLIT)
-    static constexpr bool LDSDMA = true;
-#else
-    static constexpr bool LDSDMA = false;
-#endif
     // S = 2: the half-phase weights are symmetric (L is even and x = m + 1/2 exactly), so a chain is 3 exact pair sums and
     // 3 fmafs -- the same 6 instructions, half the rounding steps: eps (and with it the near-integer fix-up rate) halves
-#ifdef LZ_MARCH_NO_SYM
-    static constexpr bool SYM = false;
-#else
     static constexpr bool SYM = S == 2;
-#endif
     // the input rows of tick t + 3 are requested a whole tick (a V pass, the barrier, an H pass) before they are committed to
     // LDS instead of one H pass before: +4 staging registers through the V pass.  Pays where LDS, not registers, limits
     // residency (16-bit samples: config 5 634 -> 617 us); on config 2 the four registers cost the fourth workgroup (224 -> 272 us)
-#if defined(LZ_MARCH_EARLY_ISSUE)
-    static constexpr bool EARLY = true;
-#elif defined(LZ_MARCH_NO_EARLY_ISSUE)
-    static constexpr bool EARLY = false;
-#else
     static constexpr bool EARLY = SB == 2;
-#endif
     // wave priority in the H pass / the V pass (0 elsewhere).  Round 1: (3, 2) beats equal priorities by 11-13 % (the H pass
     // feeds the ring every other wave's next V pass waits for).  Again with inputs from HBM (profiles/round2h_ab_wave_priority
     // .txt): config 2 (3,2) 210.5 / (3,1) 210.6 / (2,3) 212.2 / (3,3) 216.2 / (0,0) 217.4 us; config 3, whose V pass is
     // two thirds of the work, (2,3) 209.2 against (3,2) 213.8
-#if defined(LZ_MARCH_PRIO_H) && defined(LZ_MARCH_PRIO_V)
-    static constexpr int PRIO_H = LZ_MARCH_PRIO_H, PRIO_V = LZ_MARCH_PRIO_V;
-#else
     static constexpr int PRIO_H = S == 3 ? 2 : 3, PRIO_V = S == 3 ? 3 : 2;
-#endif
-#ifdef LZ_MARCH_NO_MIRROR
-    static constexpr bool MIRROR = false;
-#else
+    // S = 3: phase 2/3 mirrors phase 1/3 -- one set of weight registers serves both (fast_prepare)
     static constexpr bool MIRROR = S == 3;
-#endif
     // H pass, u8: the chain carries eps - 0.5 and the RNE byte convert is the truncating store (3-op near-integer test:
-    // fract(|acc|), subtract, unsigned min).  (S = 3: 120 -> 118 us in round 2's second half; an earlier attempt, when the
-    // kernel sat on a register step, had cost 30 %.)
-#ifdef LZ_MARCH_OLD_NEAR
-    static constexpr bool RNE_H = false;
-#elif defined(LZ_MARCH_RNE_SYM_ONLY)
-    static constexpr bool RNE_H = SB == 1 && SYM;
-#else
+    // fract(|acc|), subtract, unsigned min)
     static constexpr bool RNE_H = SB == 1;
-#endif
     // near-integer flags per SAMPLE instead of per unit: with 16-bit samples the f32 window is 2 eps ~ 0.03 (eps scales
     // with the sample range), a quarter of all units hold a flagged sample, and redoing every sample of such a unit in
     // f64 was a third of config 5's time; 8-bit configurations flag one sample in 10^4 and keep the cheaper unit flag
-#ifdef LZ_MARCH_NEAR_PER_UNIT
-    static constexpr bool NEAR_PER_SAMPLE = false;
-#else
     static constexpr bool NEAR_PER_SAMPLE = SB == 2;
-#endif
-#ifdef LZ_MARCH_NO_PK16
-    static constexpr bool PK16 = false;
-#else
-    static constexpr bool PK16 = true;   // 16-bit samples: truncating convert + unsigned min instead of med3 + floor
-#endif
-    // register budget (2nd launch bound = waves per SIMD the compiler must leave room for).  SPLIT: 4 workgroups x 6 waves
-    // = 24 waves per CU = 6 per SIMD -> 80 VGPRs; the others keep the compiler's own choice (72 for config 2 in round 1)
-#ifndef LZ_MARCH_MIN_WAVES
-#define LZ_MARCH_MIN_WAVES 6
-#endif
-#ifndef LZ_MARCH_C3_MINW
-#define LZ_MARCH_C3_MINW 1
-#endif
-    // per-lane indices rebuilt every tick from an opaque copy of the thread id instead of living in registers across the
-    // phases (what the RIDE variant does): configurations that sit just above an occupancy step
-    // (default since the march became a loop over segments: with the indices held across that loop config 2 needs 81 VGPRs
-    // -- three workgroups per CU, 310 us instead of 210 --, rebuilt per tick 68; the rebuild itself measured neutral)
-#if defined(LZ_MARCH_NO_OPAQUE)
-    static constexpr bool OPAQUE_IDX = false;
-#else
-    static constexpr bool OPAQUE_IDX = true;
-#endif
-    static constexpr int MIN_WAVES = SPLIT ? LZ_MARCH_MIN_WAVES : ((SB == 1 && C == 3 && S == 3) ? LZ_MARCH_C3_MINW : 1);
     static_assert(MS % NGRP == 0, "V groups split a tick evenly");
     static_assert(MRG * S <= 64, "the EXACT-mode redo mask has one bit per output row of a V group");
     static_assert(NGRP == 1 || NVT_PAD % 64 == 0, "V groups must be whole waves");
@@ -291,14 +153,13 @@ struct MarchCfg {
     static constexpr int WL_SMP_BITS = F::UNIT_OUT_S <= 32 ? 5 : 6;
     static constexpr int WL_UNIT_BITS = UPR <= 16 ? 4 : (UPR <= 32 ? 5 : 6);
     static_assert(F::UNIT_OUT_S <= 64 && UPR <= 64 && MS <= (1 << (16 - WL_SMP_BITS - WL_UNIT_BITS)), "worklist entry fits 16 bits");
-    static_assert(!CARRY || (NGRP == 1 && MS % TAPS == 0), "carried V window: one group, the slot rotation realigns every tick");
 };
 
 // RIDE: the launch also carries the in-place prefix rows as extra workgroups behind the marching ones (small batches:
 // no separate k_prefix launch).  That variant rebuilds its per-lane indices every tick to stay inside the register
 // budget; the batch variant (RIDE = false) holds them in registers, which is 2-3 % faster when the chip is full.
 template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
-__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::MIN_WAVES)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
+__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), 1) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
     constexpr int TAPS = K::TAPS, SB = K::SB;
@@ -429,7 +290,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     // instead of being held in registers across the other phases: the kernel sits on its 72-VGPR budget.)
     auto issue_loads_to = [&](int tick, u32x4 (&dst)[K::LOAD_IT]) {
         int t1 = tid;
-        if (LZ_RIDE_REBUILD(RIDE) || STAMP || K::SPLIT || K::OPAQUE_IDX) asm volatile("" : "+v"(t1));
+        asm volatile("" : "+v"(t1));  // (opaque copy: see the note on per-lane indices in the header comment)
 #pragma unroll
         for (int it = 0; it < K::LOAD_IT; it++) {
             const int idx = t1 + it * K::NLT;
@@ -439,16 +300,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
             const bool ok = !LZ_DBG(g, 16) && tick < ticks && idx < K::NCH && gr >= gr_min && gr <= gr_max &&
                             gr <= h_last && gb >= 0 && gb < row_bytes;
             const unsigned off = ok ? (unsigned)((gr - g.in_row0) * g.in_pitch + gb) : 0xffffffffu;
-            if (K::LDSDMA) {
-                // LDS-DMA (buffer_load_dwordx4 ... lds): the tile image is lane-linear (chunk idx at byte idx * 16), so a
-                // wave-instruction lands 1 KiB at M0 = its first chunk -- no staging registers, no ds_write, and an
-                // out-of-range lane still writes its zeros.  Straight into the buffer H(tick-2) has finished with.
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    irsrc, (__attribute__((address_space(3))) void*)(smem + (tick & 1) * K::TIN_BYTES + (wave * 64 + it * K::NLT) * 16),
-                    16, off, 0, 0, 0);
-            } else {
-                dst[it] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, LZ_MARCH_LOAD_AUX);
-            }
+            dst[it] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, off, 0, 0);
         }
     };
     auto issue_loads = [&](int tick) { issue_loads_to(tick, pre); };
@@ -458,10 +310,6 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
             *(u32x4*)(smem + buf * K::TIN_BYTES + (tid + it * K::NLT) * 16) = src[it];
     };
     auto commit_loads = [&](int buf) {
-        if (K::LDSDMA) {  // the issuing wave's vmcnt covers its LDS-DMA; the tick's barrier publishes it to the other waves
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            return;
-        }
 #pragma unroll
         for (int it = 0; it < K::LOAD_IT; it++)
             *(u32x4*)(smem + buf * K::TIN_BYTES + (tid + it * K::NLT) * 16) = pre[it];
@@ -498,7 +346,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         const uint8_t* tin = smem + (tick & 1) * K::TIN_BYTES;
         const int h0 = hb + tick * K::MS;           // first H row of the tick
         int t3 = tid;
-        if (LZ_RIDE_REBUILD(RIDE) || STAMP || K::SPLIT || K::OPAQUE_IDX) asm volatile("" : "+v"(t3));
+        asm volatile("" : "+v"(t3));
         const int row = t3 / K::UPR, u = t3 % K::UPR;
         const bool unit_ok = t3 < K::NU && h0 + row <= h_last && !LZ_DBG(g, 1);
         uint32_t im = 0;      // undecided integer-phase samples: bit (8*e*SB + i) <-> own input sample i*VEC + e
@@ -601,16 +449,11 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         // list for free (the |.| is a source modifier; v_max_f32 is a slow-class op on gfx950): black regions
                         // have acc = eps - 0.5 exactly, fract(|acc|) = 0.5 - eps, g < 0.  (Negative sums within 2 eps below
                         // -(k + 1/2) flag spuriously: the exact chain clamps like the store.)
-#ifdef LZ_MARCH_HMAX
-                        acc = __builtin_fmaxf(acc, 0.0f);
-                        const float g = __builtin_amdgcn_fractf(acc) - 0.5f;
-#else
                         const float g = __builtin_amdgcn_fractf(__builtin_fabsf(acc)) - 0.5f;
-#endif
                         const uint32_t gu = __builtin_bit_cast(uint32_t, g);
                         dminu = gu < dminu ? gu : dminu;
                         ow[o / 4] = __builtin_amdgcn_cvt_pk_u8_f32(acc, o % 4, ow[o / 4]);
-                    } else if (SB == 2 && K::PK16) {
+                    } else {
                         // 16-bit samples: acc = sum + eps.  Below 1/2 the store is 0 whatever the sum (and black regions, whose
                         // sums are exactly 0, must not look "within eps of an integer"); the float -> u32 convert truncates
                         // and an unsigned min saturates: 2.5 slow-class ops per sample instead of 4
@@ -620,14 +463,6 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         unsigned uv = (unsigned)m;                      // v_cvt_u32_f32: truncation
                         uv = uv < 65535u ? uv : 65535u;
                         ow[o / 2] |= uv << (16 * (o % 2));
-                    } else {
-                        // below 1 / above max the store clamps: nothing to decide there
-                        const float xc = __builtin_amdgcn_fmed3f(acc, 0.5f, F::MAXV + 0.5f);
-                        const float fl = __builtin_floorf(xc);
-                        if (K::NEAR_PER_SAMPLE) nearmask |= (unsigned long long)((xc - fl) < near2) << o;
-                        else dmin = __builtin_fminf(dmin, xc - fl);
-                        if (SB == 1) ow[o / 4] = __builtin_amdgcn_cvt_pk_u8_f32(fl, o % 4, ow[o / 4]);
-                        else ow[o / 2] |= (unsigned)fl << (16 * (o % 2));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -676,49 +511,10 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         const uint32_t tight = loose[i] & ~(pm & pp) & TOP;
                         im |= (tight >> (8 * SB - 1)) << i;
                     }
-                    // Second stage (8-bit samples, fc.tight2 = preconditions checked in fast_prepare): a flip of v0 also needs
-                    //     n(-2) > 2 n(-1) + 3 v0    or    ( n(+2) > 3 v0  and  n(+2) + 4 v0 + 2 > 2 n(+1) )
-                    // (the +-1 taps are positive and twice the +-2 taps; derivation: DESIGN.md 3, exhaustive check:
-                    // tests/test_integer_phase_filter.py).  On noise this takes the candidates from 23 % of the integer-phase
-                    // samples to 8 %; evaluated on 16-bit lanes (even / odd bytes), only in waves that still hold a candidate.
-                    // MEASURED (profiles/round2h_ab_second_stage_filter.txt, outputs identical): the ~170 VALU instructions per
-                    // unit cost more than the fix-ups they save -- noise 326 -> 345 us on config 2, 260 -> 268 on config 3,
-                    // gradient / blocks unchanged -- so the stage is compiled in only with -DLZ_MARCH_TIGHT2.
-#ifdef LZ_MARCH_TIGHT2
-                    constexpr bool kTight2 = true;
-#else
-                    constexpr bool kTight2 = false;
-#endif
-                    if (kTight2 && SB == 1 && A >= 3 && fc.tight2 && __any(im != 0)) {
-                        uint32_t im2 = 0;
-#pragma unroll
-                        for (int i = 0; i < F::UNIT_IN_DW; i++) {
-                            auto window_word = [&](int bo) -> uint32_t {
-                                return (bo & 3) == 0 ? wd[bo >> 2]
-                                                     : __builtin_amdgcn_alignbyte(wd[(bo >> 2) + 1], wd[bo >> 2], bo & 3);
-                            };
-                            const uint32_t w0 = wd[OWN_DW0 + i];
-                            const uint32_t wm2 = window_word(OWN_B0 + 4 * i - 2 * C), wm1 = window_word(OWN_B0 + 4 * i - C);
-                            const uint32_t wp1 = window_word(OWN_B0 + 4 * i + C), wp2 = window_word(OWN_B0 + 4 * i + 2 * C);
-                            constexpr uint32_t M = 0x00ff00ffu, B15 = 0x80008000u;
-                            uint32_t keep = 0;
-#pragma unroll
-                            for (int h = 0; h < 2; h++) {  // h = 0: bytes 0 and 2, h = 1: bytes 1 and 3 -- one 16-bit lane each
-                                const uint32_t X = (w0 >> (8 * h)) & M, N2m = (wm2 >> (8 * h)) & M, N1m = (wm1 >> (8 * h)) & M;
-                                const uint32_t N1p = (wp1 >> (8 * h)) & M, N2p = (wp2 >> (8 * h)) & M;
-                                const uint32_t V3 = X + (X << 1);
-                                // bit 15 of a lane is SET when the quantity is >= 0 (bias 0x8000, no lane ever borrows or overflows:
-                                // every quantity lies within +-1 300)
-                                const uint32_t tA = (N1m << 1) + V3 + B15 - N2m;                    // 2 n(-1) + 3 v0 - n(-2)
-                                const uint32_t t1 = V3 + B15 - N2p;                                 // 3 v0 - n(+2)
-                                const uint32_t t2 = (N1p << 1) + B15 - N2p - (X << 2) - 0x00020002u;  // 2 n(+1) - n(+2) - 4 v0 - 2
-                                const uint32_t cand = ~(tA & (t1 | t2)) & B15;  // A violated, or both B conditions violated
-                                keep |= h == 0 ? (cand >> 8) : cand;            // back to the byte lanes' top bits
-                            }
-                            im2 |= (keep >> 7) << i;
-                        }
-                        im &= im2;
-                    }
+                    // (A second stage -- necessary conditions on the +-1 neighbours too, proven in lanczos_taps.cpp:
+                    // integer_phase_tight2 and checked exhaustively in tests/test_integer_phase_filter.py -- takes the candidates on
+                    // noise from 23 % to 8 % of the integer-phase samples, but its ~170 SWAR instructions per unit cost more than
+                    // the fix-ups they save: noise 326 -> 345 us on config 2.  profiles/experiments/round3_march_variants.patch.)
                 }
             }
         }
@@ -744,7 +540,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                     const int fl = xl / S;                        // floor(x) - P0
                     const T* rp = tinT + (erow * K::IN_PITCH + F::LPB) / SB + (fl - A + 1) * C + c;
                     double sum = 0;
-                    const double* xw = (const double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL + K::LDS_HW);  // exact-chain weights
+                    const double* xw = (const double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL);  // exact-chain weights
                     if (xl - fl * S == 0) {                       // integer phase: the same weights everywhere
                         if (fc.skip_last) {  // flagged samples have v0 >= 1: the ~1e-33 tap at x-i = -a is inert, L(0) is 1
 #pragma unroll
@@ -760,10 +556,6 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         const int ph = xl - fl * S;
 #pragma unroll
                         for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * xw[ph * kMaxTaps + k];
-                    } else if (K::LDS_HW > 0) {
-                        const double* w = (const double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL) + xl * TAPS;
-#pragma unroll
-                        for (int k = 0; k < TAPS; k++) sum += (double)rp[k * C] * w[k];
                     } else {
                         const double* w = t.h_w + (size_t)xx * TAPS;
 #pragma unroll
@@ -834,31 +626,20 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     float vbias = SB == 1 ? (K::SYM ? fc.vbias_rne_p : fc.vbias_rne) : (K::SYM ? fc.bias_p : fc.bias);
     asm volatile("" : "+v"(vbias));
 
-    // SPLIT: the V window lives across ticks (the slot rotation realigns every MS = k * TAPS rows)
     float win[TAPS][F::VEC];
     uint32_t raw[TAPS];
-    if (K::CARRY) {
-#pragma unroll
-        for (int k = 0; k < TAPS; k++) {
-            raw[k] = 0;
-#pragma unroll
-            for (int e = 0; e < F::VEC; e++) win[k][e] = 0.0f;
-        }
-    }
-    // returns (per lane; lane 0 decides for the wave) whether this call issued EXACTLY MRG * S store instructions and no
-    // other vector-memory instruction: the march loop then waits for its input prefetch with a counted vmcnt
-    auto vpass = [&](int tick) -> bool {
-        int t2 = K::SPLIT ? tid - K::NHW * 64 : tid;
-        if (LZ_RIDE_REBUILD(RIDE) || STAMP || K::OPAQUE_IDX) asm volatile("" : "+v"(t2));
+    auto vpass = [&](int tick) {
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
         const int grp = K::NGRP == 1 ? (t2 < K::NVT ? 0 : 1) : grp_w;
         const int col = t2 - grp * K::NVT_PAD;
         const unsigned col_b = (unsigned)(tx * F::TWB_OUT + col * 4);
         const bool col_ok = grp < K::NGRP && col < K::NVT && col_b + 4 <= (unsigned)(g.out_w * C * SB);
-        if (!col_ok || LZ_DBG(g, 4)) return false;
+        if (!col_ok || LZ_DBG(g, 4)) return;
         constexpr int HP = K::H_PITCH / 4;
         // m handled this tick: [m_lo, m_lo + MS) with m_lo = m_b - (2a-1) + tick*MS; this group's share:
         const int m_g = m_b - (TAPS - 1) + tick * K::MS + grp * K::MRG;
-        if (m_g + K::MRG <= m_b || m_g >= m_e) return false;  // uniform
+        if (m_g + K::MRG <= m_b || m_g >= m_e) return;  // uniform
         const uint32_t* hcol = (const uint32_t*)hbuf + col;
         auto unpack = [&](int slot_i, uint32_t w) {
             raw[slot_i] = w;
@@ -871,10 +652,8 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         auto ring = [&](int r) { return hcol[K::ring_slot(r - hb) * HP]; };  // H row r of this column
         // rows m_g-a+1 .. m_g+a-1 seed the window; rows before hb were never produced: only read for m < m_b,
         // whose outputs are not stored
-        if (!K::CARRY) {
 #pragma unroll
-            for (int k = 0; k < TAPS - 1; k++) unpack(k, ring(m_g - A + 1 + k));
-        }
+        for (int k = 0; k < TAPS - 1; k++) unpack(k, ring(m_g - A + 1 + k));
         // every output row of this group's share lies inside the chunk and the stored range: no per-row tests
         const bool interior = m_g >= m_b && m_g + K::MRG <= m_e && m_g * S >= y_lo && (m_g + K::MRG) * S <= y_hi;
         const bool no_store = LZ_DBG(g, 8);
@@ -959,7 +738,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                                 }
                                 undecided = gmin < __builtin_bit_cast(uint32_t, near2);
                             }
-                        } else if (SB == 2 && !EXACT && K::PK16) {
+                        } else if (SB == 2 && !EXACT) {
                             // floor(sum + eps) clamped to [0, 65535]: max with 0, truncating convert, saturating pack
                             const unsigned u0 = (unsigned)__builtin_fmaxf(accs[0], 0.0f), u1 = (unsigned)__builtin_fmaxf(accs[1], 0.0f);
                             packed = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(u0, u1));
@@ -1011,7 +790,6 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                 __builtin_amdgcn_raw_buffer_store_b32(packed, orsrc, col_b, (y - g.out_row0) * g.out_pitch, LZ_STORE_AUX);
             }
         }
-        return interior && !EXACT && !LZ_DBG(g, 8);
     };
 
     // diagnostic build only: residency census -- when and where (XCC / SE / CU) this workgroup ran
@@ -1023,7 +801,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         census_xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
     }
     if (tid < kFastMaxS * kMaxTaps)  // exact-chain phase weights (published by the prologue's first barrier)
-        ((double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL + K::LDS_HW))[tid] = t.x_w[tid];
+        ((double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL))[tid] = t.x_w[tid];
     // =================================================================== the march, segment by segment
     unsigned long long tsum[5] = {0, 0, 0, 0, 0};  // diagnostic build only (STAMP): where a wave's cycles go
     int ticks_total = 0;
@@ -1031,52 +809,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     for (int seg = 0; seg < g.wg_segs; seg++) {
     if (!load_segment(seg)) continue;  // uniform
     ticks_total += ticks;
-    if (K::LDS_HW > 0) {  // the strip's slice of the horizontal tap table (published by the prologue's first barrier; every wave
-                          // has left the previous segment's last barrier, nobody reads the old slice any more)
-        double* hwl = (double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL);
-        for (int i = tid; i < F::TWP_OUT * TAPS; i += K::NT) {
-            int xx = tx * F::TWP_OUT + i / TAPS;
-            xx = xx < g.out_w ? xx : g.out_w - 1;
-            hwl[i] = t.h_w[(size_t)xx * TAPS + i % TAPS];
-        }
-    }
-    if (K::SPLIT) {
-        // Role-specialised waves.  Both roles pass the same barriers (one after the prologue's loads, one after H(0), one
-        // per tick); between two barriers the H waves produce tick t+1's rows in the ring while the V waves consume tick
-        // t's.  The H waves also move the input rows (prefetch two ticks ahead, commit after their H pass).
-        const bool is_h = wave < K::NHW;   // wave-uniform
-        if (is_h) {
-            issue_loads(0);
-            commit_loads(0);
-            issue_loads(1);
-            commit_loads(1);
-        }
-        __syncthreads();
-        if (is_h) hpass(0);
-        __syncthreads();
-        if (is_h) {
-            __builtin_amdgcn_s_setprio(3);  // the ring feeds every V wave's next tick: H first (measured in round 1)
-            for (int tick = 0; tick < ticks; tick++) {
-                issue_loads(tick + 2);
-                if (tick + 1 < ticks) hpass(tick + 1);
-                commit_loads(tick & 1);
-                __syncthreads();
-            }
-        } else {
-            __builtin_amdgcn_s_setprio(2);
-            for (int tick = 0; tick < ticks; tick++) {
-                vpass(tick);
-                __syncthreads();
-            }
-        }
-        continue;
-    }
-    if (K::LDSDMA) {
-        issue_loads(0);
-        commit_loads(0);
-        issue_loads(1);
-        commit_loads(1);
-    } else {  // both ticks' loads in flight at once (one memory round trip instead of two per chunk)
+    {   // both ticks' loads in flight at once (one memory round trip instead of two per chunk)
         u32x4 pre0[K::LOAD_IT];
         issue_loads_to(0, pre0);
         issue_loads(1);
@@ -1098,7 +831,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     };
     for (int tick = 0; tick < ticks; tick++) {
         const unsigned long long t0 = stamp();
-        if (!K::LDSDMA && !K::EARLY) issue_loads(tick + 2);  // lands in the buffer HPASS(tick) has finished with
+        if (!K::EARLY) issue_loads(tick + 2);  // lands in the buffer HPASS(tick) has finished with
         const unsigned long long t1 = stamp();
         // Wave priority by phase (measured, interleaved on one device: H=3/V=2/else=0 is 11-13 % faster than all
         // equal): the H pass feeds the ring every other wave's next V pass waits for, so it goes first.
@@ -1106,21 +839,15 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         if (tick + 1 < ticks) hpass(tick + 1);
         __builtin_amdgcn_s_setprio(0);
         const unsigned long long t2 = stamp();
-        // Register staging: commit BEFORE the V pass issues its stores.  LDS-DMA: the prefetch is ISSUED here, between the
-        // previous tick's stores and this tick's -- vmcnt retires in order, so after the V pass "all but the MRG * S youngest"
-        // is exactly "the prefetch has landed", and the wave never waits for a store to be acknowledged by memory (waiting
-        // with vmcnt(0) in front of the V pass stood behind the previous tick's stores: 'no loads' ablation -15 us).
-        if (K::LDSDMA) issue_loads(tick + 2);
-        else commit_loads(tick & 1);
-        if (!K::LDSDMA && K::EARLY) issue_loads(tick + 3);  // committed after the NEXT tick's H pass (see MarchCfg::EARLY)
+        // Register staging: commit BEFORE the V pass issues its stores (the staging registers must not live through the V pass).
+        // (LDS-DMA input tiles -- buffer_load ... lds, no staging registers, a counted vmcnt wait behind the V pass -- measured
+        // 7-10 % slower on config 2 wherever the DMA is issued: profiles/round3a_ab_prefix_riding_and_ldsdma_placement.txt.)
+        commit_loads(tick & 1);
+        if (K::EARLY) issue_loads(tick + 3);  // committed after the NEXT tick's H pass (see MarchCfg::EARLY)
         const unsigned long long t3 = stamp();
         __builtin_amdgcn_s_setprio(K::PRIO_V);
-        const bool full = vpass(tick);
+        vpass(tick);
         __builtin_amdgcn_s_setprio(0);
-        if (K::LDSDMA) {
-            if (__builtin_amdgcn_readfirstlane((int)full)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K::MRG * S) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         const unsigned long long t4 = stamp();
         if (!LZ_DBG(g, 128)) __syncthreads();  // (profiling bit 128: no barrier -- results are then wrong)
         const unsigned long long t5 = stamp();
@@ -1155,7 +882,7 @@ inline bool march_supports(const FrameGeom& g) {
 // ceil((R + 2a - 1) / MS) ticks: R is rounded up to "a whole number of ticks minus the window" so that no tick is spent on
 // window rows alone (16 x 1080p: 271-row chunks in 23 ticks where 276-row chunks took 24).
 inline int march_chunk_rows(int m_rows, int strips, int frames, int ms, int slots, int taps) {
-    static const int target_env = getenv("LANCZOS_MARCH_WGS") ? atoi(getenv("LANCZOS_MARCH_WGS")) : 0;
+    const int target_env = env().march_wgs;
     const int pairs = strips * frames;
     auto ticks_of = [&](int chunks) { return ((m_rows + chunks - 1) / chunks + taps - 1 + ms - 1) / ms; };
     int chunks = 1;
@@ -1205,7 +932,8 @@ inline MarchSlotSpeed march_slot_speed(int nb, int nwaves) {
     } else if (nb == 3) {
         w.full[0] = 1.05, w.full[1] = 1.0, w.full[2] = 0.95, w.shorty[0] = 1.18, w.shorty[1] = 1.10;
     }
-    if (const char* e = getenv("LANCZOS_RANK_WEIGHTS")) {
+    if (env().has_rank_weights) {
+        const char* e = env().rank_weights.c_str();
         if (atof(e) == 0.0 && e[0] == '0') {
             for (int i = 0; i < 8; i++) w.full[i] = w.shorty[i] = 1.0;
         } else {
@@ -1246,7 +974,7 @@ inline int march_build_table(std::vector<WgEntry>& tab, int* segs_out, int strip
     const int m_rows = m_hi - m_lo, slots = nb * cus, pairs = strips * frames;
     const int nx = 8, cu_x = cus / nx > 0 ? cus / nx : 1;
     const MarchSlotSpeed sp = march_slot_speed(nb, nwaves);
-    static const int segs_env = getenv("LANCZOS_MARCH_SEGS") ? atoi(getenv("LANCZOS_MARCH_SEGS")) : -1;  // 0: never mode A
+    const int segs_env = env().march_segs;  // 0: never mode A
     const int ticks_pair = (m_rows + taps - 1 + ms - 1) / ms;
     // what mode B would do with this shape
     const int rows_u = march_chunk_rows(m_rows, strips, frames, ms, slots, taps);
@@ -1353,50 +1081,8 @@ inline int march_build_table(std::vector<WgEntry>& tab, int* segs_out, int strip
             sj[j] = {v, j};
         }
         const int groups = n_x / chunks;
-        static const int band_sync = getenv("LANCZOS_BAND_SYNC") ? atoi(getenv("LANCZOS_BAND_SYNC")) : 0;
-        if (band_sync && groups % strips == 0) {
-            // Band-synchronous shares: the `strips` workgroups of one (frame, chunk) band sit on consecutive slots (mostly one
-            // rank) and ALL get the same rows, so that the strips of a frame stay on the same image rows at the same time;
-            // fast bands are paired with slow ones frame by frame.
-            const int runs = n_x / strips, frames_x = groups / strips;
-            std::vector<std::pair<double, int>> rs(runs);
-            for (int r = 0; r < runs; r++) {
-                double v = 0;
-                for (int k = 0; k < strips; k++) v += sj[r * strips + k].first;
-                rs[r] = {v / strips, r};
-            }
-            std::sort(rs.begin(), rs.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
-                return a.first != b.first ? a.first > b.first : a.second < b.second;
-            });
-            std::vector<std::vector<std::pair<double, int>>> fg(frames_x);
-            for (int i = 0; i < runs; i++) {
-                const int round = i / frames_x, pos = i % frames_x;
-                fg[(round & 1) ? frames_x - 1 - pos : pos].push_back(rs[i]);
-            }
-            for (int fi = 0; fi < frames_x; fi++) {
-                auto& mem = fg[fi];
-                std::sort(mem.begin(), mem.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.second < b.second; });
-                double tot = 0;
-                for (auto& m : mem) tot += m.first;
-                const int frame = (pair0 + fi * strips) / strips;
-                int b = m_lo;
-                double acc = 0;
-                for (size_t k = 0; k < mem.size(); k++) {
-                    acc += mem[k].first;
-                    int e;
-                    if (k + 1 == mem.size()) e = m_hi;
-                    else {
-                        const int want = (int)(m_lo + m_rows * acc / tot + 0.5) - b;
-                        e = b + march_align_rows(want, ms, taps);
-                        if (e > m_hi) e = m_hi;
-                    }
-                    for (int tx = 0; tx < strips; tx++) tab[(size_t)(mem[k].second * strips + tx) * nx + x] = WgEntry{frame, tx, b, e};
-                    b = e;
-                }
-            }
-            pair0 += groups;
-            continue;
-        }
+        // (Band-synchronous shares -- all strips of a (frame, chunk) band on the same rows -- were measured and dropped:
+        // profiles/round2g_ab_band_sync.txt.)
         std::sort(sj.begin(), sj.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
             return a.first != b.first ? a.first > b.first : a.second < b.second;
         });
@@ -1432,18 +1118,83 @@ inline int march_build_table(std::vector<WgEntry>& tab, int* segs_out, int strip
     return n;
 }
 
-// device copies of the tables a context has used (callers serialise per context; a handful of entries)
+// Resources that launches still in flight may be reading are not freed on the spot and never with a device-wide sync: an
+// event is recorded on every stream the resource was used on, and the resource is freed by a later call once those events
+// have completed (or at destruction, after waiting for them).
+struct Retired {
+    std::vector<void*> dev, host;   // hipFree / hipHostFree
+    std::vector<hipEvent_t> ev;
+};
+struct RetireList {
+    std::vector<Retired> list;
+    void retire(const std::vector<void*>& dev, const std::vector<void*>& host, const std::vector<hipStream_t>& streams) {
+        Retired r;
+        r.dev = dev;
+        r.host = host;
+        for (hipStream_t st : streams) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess && hipEventRecord(e, st) == hipSuccess) r.ev.push_back(e);
+            else if (e) (void)hipEventDestroy(e);
+        }
+        list.push_back(r);
+    }
+    void reap(bool wait) {
+        for (size_t i = 0; i < list.size();) {
+            bool done = true;
+            for (hipEvent_t e : list[i].ev) {
+                if (wait) (void)hipEventSynchronize(e);
+                else if (hipEventQuery(e) != hipSuccess) done = false;
+            }
+            if (!done) {
+                i++;
+                continue;
+            }
+            for (hipEvent_t e : list[i].ev) (void)hipEventDestroy(e);
+            for (void* p : list[i].dev) (void)hipFree(p);
+            for (void* p : list[i].host) (void)hipHostFree(p);
+            list.erase(list.begin() + i);
+        }
+    }
+    ~RetireList() { reap(true); }
+};
+inline void note_stream(std::vector<hipStream_t>& v, hipStream_t s) {
+    if (std::find(v.begin(), v.end(), s) == v.end()) v.push_back(s);
+}
+
+// device copies of the workgroup tables a context has used (callers serialise per context).  A table is built once per launch
+// shape into page-locked memory and uploaded asynchronously on the stream of its first launch; launches on other streams wait
+// for that upload by event.  Bounded: the oldest shape is retired when the 65th arrives.
 struct WgTabCache {
     struct Item {
         long long key[8];
-        WgEntry* dev;
-        int n, segs;
-        bool balanced;
+        WgEntry* dev = nullptr;
+        WgEntry* host = nullptr;           // page-locked source of the upload (stays valid while the copy is in flight)
+        int n = 0, segs = 1;
+        bool balanced = false;
+        hipEvent_t uploaded = nullptr;     // recorded behind the upload
+        hipStream_t upload_stream = nullptr;
+        std::vector<hipStream_t> streams;  // streams this shape was launched on
     };
     std::vector<Item> items;
-    ~WgTabCache() {
-        for (auto& it : items) (void)hipFree(it.dev);
+    RetireList retired;
+    void drop(size_t i) {
+        Item& it = items[i];
+        retired.retire({it.dev}, {it.host}, it.streams);
+        if (it.uploaded) (void)hipEventDestroy(it.uploaded);
+        items.erase(items.begin() + i);
     }
+    // the owner has made sure that nothing is in flight any more (lanczos_destroy: after the device has drained, before the
+    // context's streams go): free everything now -- no events on streams that may be gone by the time a destructor runs
+    void release_all() {
+        retired.reap(true);
+        for (Item& it : items) {
+            (void)hipFree(it.dev);
+            (void)hipHostFree(it.host);
+            if (it.uploaded) (void)hipEventDestroy(it.uploaded);
+        }
+        items.clear();
+    }
+    ~WgTabCache() { release_all(); }
 };
 
 template <typename T, int C, int S, int A>
@@ -1455,9 +1206,8 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     // g.prefix_K > 0 asks for the in-place prefix rows to ride on this launch (extra workgroups behind the marching
     // ones); that needs a main launch at all and the row arrays to fit the workgroup's LDS -- otherwise the caller
     // launches k_prefix
-    static const bool separate_prefix = getenv("LANCZOS_SEPARATE_PREFIX") && atoi(getenv("LANCZOS_SEPARATE_PREFIX")) != 0;
     if (g.prefix_K > 0 &&
-        (separate_prefix || (size_t)(g.prefix_M + g.prefix_M2) * K::NT * sizeof(T) > (size_t)K::LDS_BYTES ||
+        (env().separate_prefix || (size_t)(g.prefix_M + g.prefix_M2) * K::NT * sizeof(T) > (size_t)K::LDS_BYTES ||
          g.out_row0 + g.out_rows <= (g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows)))
         g.prefix_K = g.prefix_M = g.prefix_M2 = 0;
     *prefix_fused = g.prefix_K > 0;
@@ -1465,63 +1215,82 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     const int y_lo = g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows;
     const int y_hi = g.out_row0 + g.out_rows;
     if (y_lo >= y_hi) return hipSuccess;
-    std::lock_guard<std::mutex> cache_lock(launch_cache_mutex());  // slots[], attr_done[], ride_attr_done[] below
-    static int slots[2][64] = {};
-    const bool exact_ = d.mode == LANCZOS_MODE_EXACT;
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    dev_ &= 63;
-    if (slots[exact_][dev_] == 0) {
-        int nb = 0, cus = 0;
-        hipError_t e = exact_ ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march<T, C, S, A, true>, K::NT, K::LDS_BYTES)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_march<T, C, S, A, false>, K::NT, K::LDS_BYTES);
-        if (e != hipSuccess || nb < 1) nb = 1;
-        // Measured on MI355X (in-kernel stamps, profiles/): with 6-wave workgroups and ~105 SGPRs the CU admits
-        // one workgroup fewer than the API answers (waves of a workgroup land unevenly on the 4 SIMDs and the
-        // SGPR file caps waves per SIMD; MI355X_MICROARCH.md "Residency").  Sizing the grid for the API's
-        // number leaves a part-empty second round; be conservative when a workgroup is not a multiple of 4 waves.
-        if (LZ_MARCH_SGPRS == 0 && nb > 1 && K::NWAVES % 4 != 0) nb -= 1;  // with the 96-SGPR cap the API's answer holds
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || cus < 1) cus = 256;
-        slots[exact_][dev_] = nb * cus;
-        if (getenv("LANCZOS_VERBOSE"))
-            fprintf(stderr, "lanczos: k_march<%d B,%d ch,x%d,a=%d> %d threads, %d B LDS: %d workgroups/CU x %d CUs\n",
-                    (int)sizeof(T), C, S, A, K::NT, K::LDS_BYTES, nb, cus);
+    const bool exact = d.mode == LANCZOS_MODE_EXACT;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    int nb = 1, cus = 256;
+    {   // process-wide facts about this kernel instance on this device.  The lock covers only these arrays: the table cache below
+        // belongs to the context, whose calls are serialised by its own mutex.
+        std::lock_guard<std::mutex> cache_lock(launch_cache_mutex());
+        static int slots[2][64] = {};
+        static int cus_of[64] = {};
+        static bool attr_done[2][2][64] = {};  // [exact][riding][device]: dynamic LDS size set
+        if (cus_of[dev] == 0 && (hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus_of[dev] < 1))
+            cus_of[dev] = 256;
+        if (slots[exact][dev] == 0) {
+            int n = 0;
+            hipError_t e = exact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_march<T, C, S, A, true>, K::NT, K::LDS_BYTES)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_march<T, C, S, A, false>, K::NT, K::LDS_BYTES);
+            if (e != hipSuccess || n < 1) n = 1;
+            // (With the 96-SGPR cap the API's answer holds.  At the compiler's own ~105 SGPRs a CU admitted one 6-wave workgroup
+            // fewer than the API said -- waves land unevenly on the SIMDs and the SGPR file caps waves per SIMD,
+            // MI355X_MICROARCH.md "Residency" -- and the grid's second round ran part-empty.)
+            slots[exact][dev] = n * cus_of[dev];
+            if (env().verbose)
+                fprintf(stderr, "lanczos: k_march<%d B,%d ch,x%d,a=%d> %d threads, %d B LDS: %d workgroups/CU x %d CUs\n",
+                        (int)sizeof(T), C, S, A, K::NT, K::LDS_BYTES, n, cus_of[dev]);
+        }
+        for (int ride = 0; ride < 2; ride++) {
+            if (attr_done[exact][ride][dev]) continue;
+            const void* fn = exact ? (ride ? (const void*)k_march<T, C, S, A, true, false, true> : (const void*)k_march<T, C, S, A, true>)
+                                   : (ride ? (const void*)k_march<T, C, S, A, false, false, true> : (const void*)k_march<T, C, S, A, false>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr_done[exact][ride][dev] = true;
+        }
+        cus = cus_of[dev];
+        nb = slots[exact][dev] / cus > 0 ? slots[exact][dev] / cus : 1;
     }
-    static int cus_of[64] = {};
-    if (cus_of[dev_] == 0 && (hipDeviceGetAttribute(&cus_of[dev_], hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || cus_of[dev_] < 1))
-        cus_of[dev_] = 256;
-    const int nb_ = slots[exact_][dev_] / cus_of[dev_] > 0 ? slots[exact_][dev_] / cus_of[dev_] : 1;
     // the workgroup table of this launch shape (built once per context and shape)
     const int m_lo = y_lo / S, m_hi = (y_hi - 1) / S + 1;
-    const long long key[8] = {(long long)sizeof(T) | ((long long)C << 8) | ((long long)S << 16) | ((long long)A << 24) | ((long long)exact_ << 32),
-                              strips, g.frames, m_lo, m_hi, nb_, cus_of[dev_], dev_};
-    const WgTabCache::Item* item = nullptr;
-    for (const auto& it : cache->items)
+    const long long key[8] = {(long long)sizeof(T) | ((long long)C << 8) | ((long long)S << 16) | ((long long)A << 24) | ((long long)exact << 32),
+                              strips, g.frames, m_lo, m_hi, nb, cus, dev};
+    WgTabCache::Item* item = nullptr;
+    for (auto& it : cache->items)
         if (memcmp(it.key, key, sizeof(key)) == 0) item = &it;
     if (!item) {
+        cache->retired.reap(false);
         std::vector<WgEntry> tab;
-        bool balanced = false;
-        int segs = 1;
-        const int n = march_build_table(tab, &segs, strips, g.frames, m_lo, m_hi, K::MS, K::TAPS, nb_, cus_of[dev_], K::NWAVES, &balanced);
         WgTabCache::Item it;
         memcpy(it.key, key, sizeof(key));
-        it.n = n;
-        it.segs = segs;
-        it.balanced = balanced;
-        it.dev = nullptr;
-        hipError_t e = hipMalloc(&it.dev, sizeof(WgEntry) * tab.size());
-        if (e == hipSuccess) e = hipMemcpy(it.dev, tab.data(), sizeof(WgEntry) * tab.size(), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return e;
-        if (cache->items.size() >= 64) {  // bounded: drop the oldest shape (nothing in flight uses it once its stream has drained)
-            (void)hipDeviceSynchronize();
-            (void)hipFree(cache->items.front().dev);
-            cache->items.erase(cache->items.begin());
+        it.n = march_build_table(tab, &it.segs, strips, g.frames, m_lo, m_hi, K::MS, K::TAPS, nb, cus, K::NWAVES, &it.balanced);
+        const size_t bytes = sizeof(WgEntry) * tab.size();
+        hipError_t e = hipMalloc(&it.dev, bytes);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&it.host, bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&it.uploaded, hipEventDisableTiming);
+        if (e == hipSuccess) {
+            memcpy(it.host, tab.data(), bytes);
+            e = hipMemcpyAsync(it.dev, it.host, bytes, hipMemcpyHostToDevice, stream);  // stream-ordered in front of the first launch
         }
+        if (e == hipSuccess) e = hipEventRecord(it.uploaded, stream);
+        if (e != hipSuccess) {
+            if (it.dev) (void)hipFree(it.dev);
+            if (it.host) (void)hipHostFree(it.host);
+            if (it.uploaded) (void)hipEventDestroy(it.uploaded);
+            return e;
+        }
+        it.upload_stream = stream;
+        if (cache->items.size() >= 64) cache->drop(0);  // bounded: the oldest shape goes (freed once its launches have drained)
         cache->items.push_back(it);
         item = &cache->items.back();
-        if (getenv("LANCZOS_VERBOSE"))
-            fprintf(stderr, "lanczos: k_march table: %d workgroups x %d segment(s) for %d strips x %d frames, rows [%d, %d): %s shares\n", n,
-                    segs, strips, g.frames, m_lo, m_hi, balanced ? "rank-aware" : "equal");
+        if (env().verbose)
+            fprintf(stderr, "lanczos: k_march table: %d workgroups x %d segment(s) for %d strips x %d frames, rows [%d, %d): %s shares\n", item->n,
+                    item->segs, strips, g.frames, m_lo, m_hi, item->balanced ? "rank-aware" : "equal");
+    }
+    if (stream != item->upload_stream && hipEventQuery(item->uploaded) != hipSuccess) {
+        hipError_t e = hipStreamWaitEvent(stream, item->uploaded, 0);  // another stream: behind the upload
+        if (e != hipSuccess) return e;
     }
     g.wg_tab = item->dev;
     g.wg_segs = item->segs;
@@ -1529,58 +1298,29 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     g.n_main = item->n;
     g.prefix_blocks_per_frame = g.prefix_K > 0 ? (g.out_w * C + K::NT - 1) / K::NT : 0;
     // Measured (config 2, ms per step riding / separate): 1 frame 0.0198 / 0.0253, 2: 0.0281 / 0.0335, 4: 0.0464 / 0.0525,
-    // 8: 0.0687 / 0.0729, 16: 0.117-0.120 / 0.114-0.116 -- past about one prefix workgroup per CU they slow the march
-    // down more than the launch they replace.
-    {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || cus < 1) cus = 256;
-        static const bool ride_always = getenv("LANCZOS_RIDE_ALWAYS") && atoi(getenv("LANCZOS_RIDE_ALWAYS")) != 0;  // experiments
-        if (g.prefix_blocks_per_frame * g.frames > cus && !ride_always) {
-            g.prefix_K = g.prefix_M = g.prefix_M2 = g.prefix_blocks_per_frame = 0;
-            *prefix_fused = false;
-        }
+    // 8: 0.0687 / 0.0729, 16: 0.117-0.120 / 0.114-0.116, 32: 0.232 / 0.218 -- past about one prefix workgroup per CU they slow
+    // the march down more than the launch they replace (profiles/round3a_ab_prefix_riding_and_ldsdma_placement.txt).
+    if (g.prefix_blocks_per_frame * g.frames > cus) {
+        g.prefix_K = g.prefix_M = g.prefix_M2 = g.prefix_blocks_per_frame = 0;
+        *prefix_fused = false;
     }
     if (query_only) return hipSuccess;  // the caller only wanted *prefix_fused (it launches the prefix rows itself, first)
+    note_stream(item->streams, stream);
     dim3 grid(g.n_main + g.prefix_blocks_per_frame * g.frames);
-    static const int extra_lds = getenv("LANCZOS_EXTRA_LDS") ? atoi(getenv("LANCZOS_EXTRA_LDS")) : 0;  // occupancy experiments
-    static bool attr_done[2][64] = {};
-    const bool exact = d.mode == LANCZOS_MODE_EXACT;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev &= 63;
-    if (!attr_done[exact][dev]) {
-        hipError_t e = exact ? hipFuncSetAttribute((const void*)k_march<T, C, S, A, true>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + extra_lds)
-                             : hipFuncSetAttribute((const void*)k_march<T, C, S, A, false>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + extra_lds);
-        if (e != hipSuccess) return e;
-        attr_done[exact][dev] = true;
-    }
     if (*prefix_fused) {
-        static bool ride_attr_done[2][64] = {};
-        if (!ride_attr_done[exact][dev]) {
-            hipError_t e = exact ? hipFuncSetAttribute((const void*)k_march<T, C, S, A, true, false, true>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + extra_lds)
-                                 : hipFuncSetAttribute((const void*)k_march<T, C, S, A, false, false, true>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES + extra_lds);
-            if (e != hipSuccess) return e;
-            ride_attr_done[exact][dev] = true;
-        }
-        if (exact)
-            hipLaunchKernelGGL((k_march<T, C, S, A, true, false, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
-        else
-            hipLaunchKernelGGL((k_march<T, C, S, A, false, false, true>), grid, dim3(K::NT), K::LDS_BYTES + extra_lds, stream, g, t,
-                               fc);
+        if (exact) hipLaunchKernelGGL((k_march<T, C, S, A, true, false, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
+        else hipLaunchKernelGGL((k_march<T, C, S, A, false, false, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
         return hipGetLastError();
     }
-    if (exact)
-        hipLaunchKernelGGL((k_march<T, C, S, A, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
-    else if (g.stamps && sizeof(T) == 1 && C == 3 && S == 2 && A == 3) {  // diagnostic build, one configuration
+#ifdef LZ_PROFILE_BITS
+    if (!exact && g.stamps && sizeof(T) == 1 && C == 3 && S == 2 && A == 3) {  // diagnostic build, one configuration
         using KS = MarchCfg<uint8_t, 3, 2, 3>;
         hipLaunchKernelGGL((k_march<uint8_t, 3, 2, 3, false, true>), grid, dim3(KS::NT), KS::LDS_BYTES, stream, g, t, fc);
+        return hipGetLastError();
     }
-    else
-        hipLaunchKernelGGL((k_march<T, C, S, A, false>), grid, dim3(K::NT), K::LDS_BYTES + extra_lds, stream, g, t, fc);
+#endif
+    if (exact) hipLaunchKernelGGL((k_march<T, C, S, A, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
+    else hipLaunchKernelGGL((k_march<T, C, S, A, false>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
     return hipGetLastError();
 }
 

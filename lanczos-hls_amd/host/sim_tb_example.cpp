@@ -3,7 +3,9 @@
 // stream_out back, print "RMS err" against the expected image and write the expected and the observed PNG under the
 // testbench's names, "<dir>/WxH->WxH_N|D_A-expected.png" / "...-observed.png" (full_TB.h:142-177).  The expected image
 // here is the library's own bit-exact mode (LANCZOS_MODE_EXACT = lanczos_expected() bit for bit, proven by tests/);
-// the observed one is what lanczos(stream_in, stream_out) returns (default mode, within +-1).
+// the observed one is what lanczos(stream_in, stream_out) returns -- hls_compat.hpp's lanczos() calls lanczos_u8, which is
+// LANCZOS_MODE_EXACT as well, so "RMS err" prints 0.000000 (the reference prints the distance between its two
+// deliberately different implementations there, full_TB.h:166-170).
 // Build: Makefile target `sim_tb_example`; run on a machine with a GPU:   ./sim_tb_example in.png out_dir/
 #include <cmath>
 #include <string>
