@@ -556,7 +556,7 @@ static hipError_t launch_prefix_front(const lanczos_desc* d, const lz::FrameGeom
 
 // the resample proper; ctx->mu is held by the caller
 static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const void* d_in, void* d_out, int frames,
-                                  size_t in_frame_stride, size_t out_frame_stride, void* stream_v) {
+                                  size_t in_frame_stride, size_t out_frame_stride, void* stream_v, bool in_split = false) {
     int rc;
     LZ_HIP(ctx, hipSetDevice(ctx->device));
     Plan* p = nullptr;
@@ -666,6 +666,23 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
             e = lz::fast_launch(*d, g, p->dev, p->fast, stream);
         } else {
             lz::FrameGeom gm = g;
+            if (!ctx->timing && !in_split) {
+                // A batch of twice the kernel's preferred size or more goes out as several launches of that size: one resident
+                // round of workgroups with two chunks per (strip, frame) pair is the fastest shape this kernel has.
+                bool dummy = false;
+                e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &dummy, &ctx->wg_tabs, /*query_only=*/true);
+                const int pf = ctx->wg_tabs.pref_frames;
+                if (e == hipSuccess && pf >= 8 && frames >= 2 * pf) {
+                    for (int f0 = 0; f0 < frames; f0 += pf) {
+                        const int nf = frames - f0 < pf ? frames - f0 : pf;
+                        rc = resample_device_locked(ctx, d, (const uint8_t*)d_in + (size_t)f0 * g.in_frame_stride,
+                                                    (uint8_t*)d_out + (size_t)f0 * g.out_frame_stride, nf, g.in_frame_stride,
+                                                    g.out_frame_stride, stream_v, /*in_split=*/true);
+                        if (rc != LANCZOS_OK) return rc;
+                    }
+                    return LANCZOS_OK;
+                }
+            }
             if (has_prefix) {  // ask the marching launch to carry the prefix rows too (no separate k_prefix launch)
                 gm.prefix_K = p->prefix.K;
                 gm.prefix_M = p->prefix.M;

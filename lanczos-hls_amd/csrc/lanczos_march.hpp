@@ -1177,6 +1177,11 @@ struct WgTabCache {
     };
     std::vector<Item> items;
     RetireList retired;
+    // set by every march_launch (query or launch): the batch size this kernel instance runs best at for this frame width -- the
+    // largest one whose (strip, frame) pairs, cut in two chunks each, fill ONE resident round of workgroups with rank-aware
+    // shares (config 2: 32 frames = 960 workgroups on 1 024 slots).  Larger batches are faster as several launches of this size
+    // (64 frames: 2 x 207 us against 502 us in one launch, profiles/round3g_bench_default.json); 0: no preference
+    int pref_frames = 0;
     void drop(size_t i) {
         Item& it = items[i];
         retired.retire({it.dev}, {it.host}, it.streams);
@@ -1251,6 +1256,11 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
         }
         cus = cus_of[dev];
         nb = slots[exact][dev] / cus > 0 ? slots[exact][dev] / cus : 1;
+    }
+    {
+        int pf = (nb * cus) / (2 * strips);
+        while (pf > 0 && (2 * strips * pf) % 16 != 0) pf--;   // every XCD gets whole pairs of chunks (march_build_table: balanced)
+        cache->pref_frames = pf;
     }
     // the workgroup table of this launch shape (built once per context and shape)
     const int m_lo = y_lo / S, m_hi = (y_hi - 1) / S + 1;

@@ -265,6 +265,28 @@ def test_batch_of_frames(ctx):
         assert np.array_equal(got[i], _oracle(frames[i], 2, 1, 3))
 
 
+def test_oversized_batch_goes_out_as_several_launches(ctx):
+    """A device batch of twice the marching kernel's preferred size or more (1920-wide RGB8 2x: 32 frames) is split into
+    launches of that size inside lanczos_resample_device; 70 frames = 32 + 32 + 6, every frame against the oracle's frame
+    (the frames are short, the width is config 2's: 15 strips)."""
+    import torch
+    w, h, f = 1920, 20, 70
+    base = [P.noise(h, w, 3, seed=900 + i) for i in range(3)]
+    frames = np.stack([base[i % 3] for i in range(f)])
+    frames[:, 0, 0, 0] = np.arange(f, dtype=np.uint8)          # every frame differs somewhere
+    d = L.make_desc(w, h, 3, 2, 1, 3, 1, L.MODE_EXACT)
+    x = torch.from_numpy(frames).cuda()
+    y = torch.zeros((f, d.out_h, d.out_w, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.resample_device(d, x.data_ptr(), y.data_ptr(), f, 0, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = y.cpu().numpy()
+    for i in (0, 1, 31, 32, 33, 63, 64, 69):
+        assert np.array_equal(got[i], _oracle(frames[i], 2, 1, 3)), i
+    one = ctx.resample(frames[:40], 2, 1, 3, L.MODE_EXACT)       # below twice the preferred size: one launch, same bytes
+    assert np.array_equal(one, got[:40])
+
+
 def test_row_strips_reassemble_to_the_whole_frame(ctx):
     """BASELINE config 5's sharding: output row strips with an input halo, no other exchange."""
     for (w, h, c, sn, sd, a, dtype) in [(96, 128, 4, 2, 1, 4, np.uint16), (120, 96, 3, 3, 1, 3, np.uint8),
