@@ -361,12 +361,17 @@ def main():
         return max_over_ranks(dt)
 
     # Untimed: let the device reach its steady clocks before the W warm-up steps.  A fresh box runs the first
-    # ~30 ms of work 10-15 % slower (measured: 150 us per launch with 5 warm-up launches, 132 us after 200).
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.settle_s:
-        for _ in range(20):
-            wl.step()
-        torch.cuda.synchronize()
+    # ~30 ms of work 10-15 % slower (measured: 150 us per launch with 5 warm-up launches, 132 us after 200).  The same settling
+    # precedes every side measurement below (other patterns / batches / configs): timed right behind a refill with three warm
+    # steps, "blocks" read 236-242 us per step where the interleaved A/B harness (30 warm steps) reads 213.
+    def settle(w, seconds):
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < seconds:
+            for _ in range(20):
+                w.step()
+            torch.cuda.synchronize()
+
+    settle(wl, args.settle_s)
     for _ in range(args.warmup):
         wl.step()
 
@@ -392,9 +397,8 @@ def main():
             if pat == args.pattern:
                 continue
             wl.refill(pat, 4321 + (rank if shard == "frames" else 0))
-            for _ in range(3):
-                wl.step()
-            s_o = device_batch_time(torch, wl, max(10, args.steps // 2))
+            settle(wl, min(args.settle_s, 0.1))
+            s_o = sorted(device_batch_time(torch, wl, max(10, args.steps // 2)) for _ in range(3))[1]
             others[pat] = {"step_us": round(s_o * 1e6, 2),
                            "roofline_frac": round(wl.alg_bytes / s_o / 1e9 / HBM_PEAK_GBS, 4)}
         extra["other_patterns"] = others
@@ -409,9 +413,8 @@ def main():
                 if f < 1:
                     continue
                 wl.frames = f
-                for _ in range(3):
-                    wl.step()
-                s_b = device_batch_time(torch, wl, max(10, args.steps // 2))
+                settle(wl, min(args.settle_s, 0.05))
+                s_b = sorted(device_batch_time(torch, wl, max(10, args.steps // 2)) for _ in range(3))[1]
                 batches[str(f)] = {"step_us": round(s_b * 1e6, 2),
                                    "roofline_frac": round(wl.alg_bytes * f / full_frames / s_b / 1e9 / HBM_PEAK_GBS, 4)}
             wl.frames = full_frames
@@ -437,9 +440,7 @@ def main():
             in_b = f_o * cfg_o[0] * cfg_o[1] * cfg_o[2] * cfg_o[3]
             rot_o = min(8, max(1, -(-2 * 256 * 2**20 // in_b)))
             w_o = Workload(torch, L, ctx, cfg_o, f_o, mode, args.pattern, device, rank, world, "frames", 4000, rot_o)
-            for _ in range(max(6, 2 * rot_o)):
-                w_o.step()
-            torch.cuda.synchronize()
+            settle(w_o, min(args.settle_s, 0.1))
             n_o = max(10, args.steps // 2)
             s_o = sorted(device_batch_time(torch, w_o, n_o) for _ in range(3))[1]
             others_cfg[f"{name}_{f_o}_frames"] = {
