@@ -145,6 +145,15 @@ struct MarchCfg {
     // with the sample range), a quarter of all units hold a flagged sample, and redoing every sample of such a unit in
     // f64 was a third of config 5's time; 8-bit configurations flag one sample in 10^4 and keep the cheaper unit flag
     static constexpr bool NEAR_PER_SAMPLE = SB == 2;
+    // Register budget (2nd launch bound = waves per SIMD the compiler must leave room for).  6-wave workgroups land 2+2+1+1 on
+    // the four SIMDs from a varying start, so four of them only fit reliably when a SIMD may hold SEVEN waves: 72 VGPRs.
+    // Configurations the compiler leaves just above that step are told to stay under it.
+    static constexpr int MIN_WAVES = (SB == 1 && S == 2 && A == 3 && NT == 384) ? 7 : 1;
+    // Per-lane address parts of the input loads and of the H unit held in registers for a whole segment (a tick adds one scalar)
+    // instead of being rebuilt every tick from the thread id (~35 VALU instructions, six of them quarter-rate multiplies).
+    // Worth 1.5-2 % where the three registers fit under the occupancy step (config 2: 218 -> 214.5 us, profiles/
+    // round3k_ab_hoisted_lane_constants.txt); where they do not, the rebuild stays (config 3: 75 -> 85 VGPRs, 217 -> 309 us).
+    static constexpr bool HOIST = MIN_WAVES > 1;
     static_assert(MS % NGRP == 0, "V groups split a tick evenly");
     static_assert(MRG * S <= 64, "the EXACT-mode redo mask has one bit per output row of a V group");
     static_assert(NGRP == 1 || NVT_PAD % 64 == 0, "V groups must be whole waves");
@@ -159,7 +168,7 @@ struct MarchCfg {
 // no separate k_prefix launch).  That variant rebuilds its per-lane indices every tick to stay inside the register
 // budget; the batch variant (RIDE = false) holds them in registers, which is 2-3 % faster when the chip is full.
 template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
-__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), 1) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
+__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (EXACT ? (MarchCfg<T, C, S, A>::MIN_WAVES > 1 ? 6 : 1) : MarchCfg<T, C, S, A>::MIN_WAVES)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
     constexpr int TAPS = K::TAPS, SB = K::SB;
@@ -286,11 +295,39 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), 1) LZ_MARCH_SGPR_ATTR v
 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 pre[K::LOAD_IT];
-    // (RIDE: per-lane indices are rebuilt every tick from an opaque copy of the thread id -- a handful of instructions --
-    // instead of being held in registers across the other phases: the kernel sits on its 72-VGPR budget.)
-    auto issue_loads_to = [&](int tick, u32x4 (&dst)[K::LOAD_IT]) {
+    // Per-lane address parts live in registers for the whole segment; a tick adds one scalar.  (Rebuilding them every tick from
+    // the thread id cost ~35 VALU instructions per tick, six of them quarter-rate multiplies (v_mul_lo_u32, v_mul_hi_i32,
+    // v_mad_u64_u32) -- 12 % of a kernel whose VALU pipes are busy 100 % of the time, profiles/round3_sq_counters.json.)
+    //   ld_const: row * in_pitch + byte offset of the lane's 16-byte chunk; 0x80000000 for a lane that never loads (beyond the
+    //   tile, left / right of the image).  offset = ld_const + (first row of the tick - in_row0) * in_pitch.  Rows above the
+    //   buffer give a negative sum = a huge unsigned offset, rows below it an offset >= num_records: the descriptor's range check
+    //   returns zeros for both (a dropped tap), and 0x80000000 plus any such scalar stays out of range (buffers < 2^30 bytes:
+    //   march_supports).
+    unsigned ld_const[K::LOAD_IT];
+    auto set_load_consts = [&]() {  // per segment (tile_gb0 changes with the strip)
+        if (!K::HOIST) return;
         int t1 = tid;
-        asm volatile("" : "+v"(t1));  // (opaque copy: see the note on per-lane indices in the header comment)
+        asm volatile("" : "+v"(t1));
+#pragma unroll
+        for (int it = 0; it < K::LOAD_IT; it++) {
+            const int idx = t1 + it * K::NLT;
+            const int row = idx / K::CPR, ch = idx - row * K::CPR;
+            const int gb = tile_gb0 + 16 * ch;
+            const bool ok = !LZ_DBG(g, 16) && idx < K::NCH && gb >= 0 && gb < row_bytes;
+            ld_const[it] = ok ? (unsigned)(row * g.in_pitch + gb) : 0x80000000u;
+            asm volatile("" : "+v"(ld_const[it]));
+        }
+    };
+    auto issue_loads_to = [&](int tick, u32x4 (&dst)[K::LOAD_IT]) {
+        if (K::HOIST) {
+            // uniform: past the segment's last tick nothing is fetched (0x40000000 puts every lane out of range)
+            const unsigned s_off = tick < ticks ? (unsigned)((hb + tick * K::MS - g.in_row0) * g.in_pitch) : 0x40000000u;
+#pragma unroll
+            for (int it = 0; it < K::LOAD_IT; it++) dst[it] = __builtin_amdgcn_raw_buffer_load_b128(irsrc, ld_const[it] + s_off, 0, 0);
+            return;
+        }
+        int t1 = tid;
+        asm volatile("" : "+v"(t1));  // (indices rebuilt from an opaque copy of the thread id: nothing held across the phases)
 #pragma unroll
         for (int it = 0; it < K::LOAD_IT; it++) {
             const int idx = t1 + it * K::NLT;
@@ -342,28 +379,44 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), 1) LZ_MARCH_SGPR_ATTR v
     asm volatile("" : "+v"(hbias));
 
     // =================================================================== HPASS + FIXUP of one tick
+    // The H unit of this thread.  Its output sits at byte tid * UNIT_OUT bytes of a ring-row block (a ring row is UPR units wide:
+    // row * H_PITCH + u * UNIT_OUT_DW * 4 == tid * UNIT_OUT_DW * 4), one full-rate multiply per tick, and that offset doubles as
+    // the row test (unit rows r < n <=> offset < n * H_PITCH).  The input window's LDS offset (rows are IN_PITCH apart, not a
+    // multiple of the unit) is kept in a register.
+    static_assert(K::H_PITCH == K::UPR * F::UNIT_OUT_DW * 4, "a ring row is exactly UPR units");
+    unsigned h_in_const = 0;
+    if (K::HOIST) {
+        const int row = tid / K::UPR, u = tid % K::UPR;
+        h_in_const = (unsigned)((row * (K::IN_PITCH / 4) + F::WIN_DW0 + u * F::UNIT_IN_DW) * 4);
+        asm volatile("" : "+v"(h_in_const));
+    }
     auto hpass = [&](int tick) {
         const uint8_t* tin = smem + (tick & 1) * K::TIN_BYTES;
         const int h0 = hb + tick * K::MS;           // first H row of the tick
+        const int rows_here = h_last - h0 + 1 < K::MS ? h_last - h0 + 1 : K::MS;  // uniform; <= 0: nothing left
         int t3 = tid;
-        asm volatile("" : "+v"(t3));
-        const int row = t3 / K::UPR, u = t3 % K::UPR;
-        const bool unit_ok = t3 < K::NU && h0 + row <= h_last && !LZ_DBG(g, 1);
+        if (!K::HOIST) asm volatile("" : "+v"(t3));
+        const unsigned h_out_const = (unsigned)t3 * (unsigned)(F::UNIT_OUT_DW * 4);  // (HOIST: tid < 1024, one v_mul_u32_u24)
+        const bool unit_ok = rows_here > 0 && h_out_const < (unsigned)(rows_here * K::H_PITCH) && (K::NU >= K::NT || t3 < K::NU) &&
+                             !LZ_DBG(g, 1);
         uint32_t im = 0;      // undecided integer-phase samples: bit (8*e*SB + i) <-> own input sample i*VEC + e
         bool near = false;    // some non-integer-phase sample of the unit is within eps of an integer
         unsigned long long nearmask = 0;  // NEAR_PER_SAMPLE: which ones (bit = output sample of the unit)
         if (unit_ok) {
             const uint32_t* tin32 = (const uint32_t*)tin;
             uint32_t wd[F::NW];
-            const uint32_t* wp = tin32 + row * (K::IN_PITCH / 4) + F::WIN_DW0 + u * F::UNIT_IN_DW;
+            const uint32_t* wp = K::HOIST ? (const uint32_t*)(tin + h_in_const)
+                                          : tin32 + (t3 / K::UPR) * (K::IN_PITCH / 4) + F::WIN_DW0 + (t3 % K::UPR) * F::UNIT_IN_DW;
 #pragma unroll
             for (int i = 0; i < F::NW; i++) wd[i] = wp[i];
             // Output dwords start as the integer-phase samples (copies of input bytes: one v_perm_b32 when they come
             // from <= 2 window dwords); the computed samples are inserted as they are produced.  One CHANNEL at a
             // time, fenced, so that only WIN_PX converted samples are live at once (registers, not ILP, are scarce:
             // <= 64 VGPRs lets every SIMD hold 8 waves, which is what makes 4 workgroups per CU always placeable).
-            const int slot = K::ring_slot(h0 + row - hb);
-            uint32_t* hp = (uint32_t*)hbuf + slot * (K::H_PITCH / 4) + u * F::UNIT_OUT_DW;
+            // ring slot of the unit's row = (slot of the tick's first row + row) mod RS: one add and an unsigned min
+            unsigned hofs = h_out_const + (unsigned)(K::ring_slot(h0 - hb) * K::H_PITCH);
+            hofs = hofs < hofs - (unsigned)(K::RS * K::H_PITCH) ? hofs : hofs - (unsigned)(K::RS * K::H_PITCH);
+            uint32_t* hp = (uint32_t*)(hbuf + hofs);
             uint32_t ow[F::UNIT_OUT_DW];
 #pragma unroll
             for (int i = 0; i < F::UNIT_OUT_DW; i++) {
@@ -566,6 +619,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), 1) LZ_MARCH_SGPR_ATTR v
                 }
                 cnt = 0;
             };
+            const int row = t3 / K::UPR, u = t3 % K::UPR;  // (only needed on this rare path)
             const unsigned ent0 = ((unsigned)row << (K::WL_SMP_BITS + K::WL_UNIT_BITS)) | ((unsigned)u << K::WL_SMP_BITS);
             auto append = [&](bool flag, int o) {  // o wave-uniform: output sample of the unit
                 const unsigned long long m = __ballot(flag);
@@ -809,6 +863,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), 1) LZ_MARCH_SGPR_ATTR v
     for (int seg = 0; seg < g.wg_segs; seg++) {
     if (!load_segment(seg)) continue;  // uniform
     ticks_total += ticks;
+    set_load_consts();
     {   // both ticks' loads in flight at once (one memory round trip instead of two per chunk)
         u32x4 pre0[K::LOAD_IT];
         issue_loads_to(0, pre0);
@@ -872,7 +927,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), 1) LZ_MARCH_SGPR_ATTR v
 // the marching kernel moves whole 16-byte chunks: rows, frames and the base must be 16-byte multiples
 inline bool march_supports(const FrameGeom& g) {
     return g.in_pitch % 16 == 0 && (((uintptr_t)g.in) & 15) == 0 && (g.in_frame_stride & 15) == 0 &&
-           (size_t)g.in_pitch * g.in_rows < (1ull << 31);
+           (size_t)g.in_pitch * g.in_rows < (1ull << 30);  // (the hoisted load offsets' out-of-range markers need the two top bits)
 }
 
 // Chunk height: ONE resident round of workgroups.  With more workgroups than the chip holds at once the second
