@@ -147,7 +147,8 @@ struct MarchCfg {
     static constexpr bool NEAR_PER_SAMPLE = SB == 2;
     // Register budget (2nd launch bound = waves per SIMD the compiler must leave room for).  6-wave workgroups land 2+2+1+1 on
     // the four SIMDs from a varying start, so four of them only fit reliably when a SIMD may hold SEVEN waves: 72 VGPRs.
-    // Configurations the compiler leaves just above that step are told to stay under it.
+    // Configurations the compiler leaves just above that step are told to stay under it -- the EXACT variants too, whose 9
+    // spilled dwords sit on the cold f64 redo path (84 VGPRs, 388 us -> 72 VGPRs, 330 us per 32 frames of config 2).
     static constexpr int MIN_WAVES = (SB == 1 && S == 2 && A == 3 && NT == 384) ? 7 : 1;
     // Per-lane address parts of the input loads and of the H unit held in registers for a whole segment (a tick adds one scalar)
     // instead of being rebuilt every tick from the thread id (~35 VALU instructions, six of them quarter-rate multiplies).
@@ -168,7 +169,7 @@ struct MarchCfg {
 // no separate k_prefix launch).  That variant rebuilds its per-lane indices every tick to stay inside the register
 // budget; the batch variant (RIDE = false) holds them in registers, which is 2-3 % faster when the chip is full.
 template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
-__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (EXACT ? (MarchCfg<T, C, S, A>::MIN_WAVES > 1 ? 6 : 1) : MarchCfg<T, C, S, A>::MIN_WAVES)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
+__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), MarchCfg<T, C, S, A>::MIN_WAVES) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
     constexpr int TAPS = K::TAPS, SB = K::SB;
