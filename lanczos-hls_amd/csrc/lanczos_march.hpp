@@ -895,7 +895,9 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         if (tick + 1 < ticks) hpass(tick + 1);
         __builtin_amdgcn_s_setprio(0);
         const unsigned long long t2 = stamp();
-        // Register staging: commit BEFORE the V pass issues its stores (the staging registers must not live through the V pass).
+        // Register staging: commit BEFORE the V pass issues its stores (the staging registers must not live through the V pass:
+        // committing behind it -- the rows get the H pass and the V pass to arrive, no wait -- spills 5 dwords in this loop at the
+        // 72-VGPR budget: 207 -> 235 us, profiles/round3n_ab_commit_behind_v_pass.txt).
         // (LDS-DMA input tiles -- buffer_load ... lds, no staging registers, a counted vmcnt wait behind the V pass -- measured
         // 7-10 % slower on config 2 wherever the DMA is issued: profiles/round3a_ab_prefix_riding_and_ldsdma_placement.txt.)
         commit_loads(tick & 1);
