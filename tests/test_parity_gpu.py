@@ -287,6 +287,39 @@ def test_oversized_batch_goes_out_as_several_launches(ctx):
     assert np.array_equal(one, got[:40])
 
 
+def test_bounded_caches_survive_many_shapes():
+    """The plan cache (32 shapes) and the marching kernel's table cache (64 launch shapes) retire their oldest entries by
+    event instead of growing: 40 frame shapes and 70 batch sizes through ONE context, results still the oracle's, and the
+    context tears down cleanly with retired entries pending."""
+    import torch
+    c = L.Context(0)
+    try:
+        first = None
+        for i in range(40):                                  # 40 plans > kMaxPlans
+            w, h = 64 + 16 * i, 24 + (i % 5)
+            img = P.noise(h, w, 3, seed=300 + i)
+            got = c.resample(img, 2, 1, 3, L.MODE_EXACT)
+            if i in (0, 17, 39):
+                assert np.array_equal(got, _oracle(img, 2, 1, 3)), i
+            if i == 0:
+                first = (img, got)
+        assert np.array_equal(c.resample(first[0], 2, 1, 3, L.MODE_EXACT), first[1])   # the retired plan is rebuilt
+        d = L.make_desc(208, 40, 3, 2, 1, 3, 1, L.MODE_EXACT)
+        frames = np.stack([P.noise(40, 208, 3, seed=77)] * 70)
+        x = torch.from_numpy(frames).cuda()
+        y = torch.zeros((70, d.out_h, d.out_w, 3), dtype=torch.uint8, device="cuda")
+        want = _oracle(frames[0], 2, 1, 3)
+        st = torch.cuda.current_stream().cuda_stream
+        for f in range(1, 71):                               # 70 launch shapes > 64 tables; no sync in between
+            c.resample_device(d, x.data_ptr(), y.data_ptr(), f, 0, 0, st)
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        for f in (0, 35, 69):
+            assert np.array_equal(got[f], want), f
+    finally:
+        c.close()
+
+
 def test_row_strips_reassemble_to_the_whole_frame(ctx):
     """BASELINE config 5's sharding: output row strips with an input halo, no other exchange."""
     for (w, h, c, sn, sd, a, dtype) in [(96, 128, 4, 2, 1, 4, np.uint16), (120, 96, 3, 3, 1, 3, np.uint8),
