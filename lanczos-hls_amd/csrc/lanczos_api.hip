@@ -252,7 +252,7 @@ const char* lanczos_strerror(int code) {
     switch (code) {
         case LANCZOS_OK: return "ok";
         case LANCZOS_ERR_BAD_ARG: return "bad argument (null pointer, size, channels, a, or out != in*N/D)";
-        case LANCZOS_ERR_UNSUPPORTED: return "unsupported configuration (scale <= 1 or in-place prefix too deep)";
+        case LANCZOS_ERR_UNSUPPORTED: return "unsupported configuration (scale < 1 or in-place prefix too deep)";
         case LANCZOS_ERR_NO_DEVICE: return "no HIP device";
         case LANCZOS_ERR_HIP: return "HIP runtime error";
         case LANCZOS_ERR_NOMEM: return "out of memory";

@@ -112,8 +112,11 @@ int validate(const lanczos_desc* d) {
     if (d->out_row0 < 0 || d->out_rows < 0) return LANCZOS_ERR_BAD_ARG;
     if (d->out_rows == 0 && d->out_row0 != 0) return LANCZOS_ERR_BAD_ARG;
     if (d->out_row0 + d->out_rows > d->out_h) return LANCZOS_ERR_BAD_ARG;
-    // S <= 1: the in-place vertical pass of full_TB.h:67-77 would read written rows everywhere
-    if (d->scale_n <= d->scale_d) return LANCZOS_ERR_UNSUPPORTED;
+    // S < 1: the reference itself is out of bounds there (full_TB.h:85 writes img_out[j][i] for i < IN_HEIGHT into an array of
+    // OUT_HEIGHT rows).  S == 1 is well defined -- every sample sits on an integer phase and the in-place vertical pass
+    // (full_TB.h:67-77) is ONE recurrence over the whole frame height per column -- and runs wherever that recurrence fits the
+    // in-place-prefix kernel (frames up to kMaxPrefixRows rows; deeper ones: LANCZOS_ERR_UNSUPPORTED from the resample call).
+    if (d->scale_n < d->scale_d) return LANCZOS_ERR_UNSUPPORTED;
     return LANCZOS_OK;
 }
 

@@ -215,8 +215,20 @@ def test_scales_close_to_one_deep_inplace_prefix(ctx):
         want = _oracle(img, sn, sd, a)
         for mode in (L.MODE_EXACT, L.MODE_LSB1):
             _cmp(ctx.resample(img, sn, sd, a, mode), want, mode, f"deep prefix {sn}/{sd} K={K}")
-    with pytest.raises(L.LanczosError) as e:       # S = 1 (and below): refused, see DESIGN.md
-        ctx.resample(P.noise(16, 16, 3), 4, 4, 3)
+    # S = 1: every sample on an integer phase, the in-place pass one recurrence over the whole height per column
+    # (full_TB.h:67-77) -- the output is the input except where the double noise of the ~1e-17 taps flips a dark sample
+    for (w, h, c, a, gen) in [(64, 48, 3, 3, P.dark_noise), (40, 200, 1, 3, P.dark_noise), (33, 21, 4, 4, P.noise), (96, 64, 3, 2, P.noise)]:
+        img = gen(h, w, c, seed=5)
+        want = _oracle(img, 4, 4, a)                # reduced to 1/1 by the gcd, like lanczos.h:110
+        assert want.shape == img.shape
+        for mode in (L.MODE_EXACT, L.MODE_LSB1):
+            _cmp(ctx.resample(img, 4, 4, a, mode), want, mode, f"S=1 {w}x{h}x{c} a={a}")
+    assert (_oracle(P.dark_noise(48, 64, 3, seed=5), 1, 1, 3) != P.dark_noise(48, 64, 3, seed=5)).any()   # (the quirk is exercised)
+    with pytest.raises(L.LanczosError) as e:       # ... up to the prefix kernel's depth; S < 1: refused (the reference is out of bounds)
+        ctx.resample(P.noise(1100, 16, 3), 1, 1, 3)
+    assert e.value.code == L.ERR_UNSUPPORTED
+    with pytest.raises(L.LanczosError) as e:
+        ctx.resample(P.noise(16, 16, 3), 3, 4, 3)
     assert e.value.code == L.ERR_UNSUPPORTED
 
 
@@ -357,8 +369,10 @@ def test_reference_call_shape_and_errors(ctx):
     with pytest.raises(L.LanczosError) as e:
         ctx.u8(img, 130, 96, 3)          # wrong output size: full_TB.h:115-118
     assert e.value.code == L.ERR_BAD_ARG
+    same = ctx.u8(img, 64, 48, 3)        # scale 1 (round 3): the reference's identity-scale result, not an error
+    _cmp(same, _oracle(img, 1, 1, 3), L.MODE_EXACT, "lanczos_u8 1/1")
     with pytest.raises(L.LanczosError) as e:
-        ctx.u8(img, 64, 48, 3)           # scale 1: unsupported
+        ctx.u8(np.ascontiguousarray(img[:, :60]), 40, 32, 3)   # scale 2/3: the reference is out of bounds there (full_TB.h:85)
     assert e.value.code == L.ERR_UNSUPPORTED
     with pytest.raises(L.LanczosError):
         ctx.resample(np.zeros((4, 4, 2), np.uint8), 2, 1, 3)   # 2 channels
