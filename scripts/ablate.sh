@@ -1,4 +1,6 @@
 #!/usr/bin/env bash
+# NEEDS the profiling build: make -C lanczos-hls_amd variant VARIANT=prof EXTRA=-DLZ_PROFILE_BITS and LANCZOS_LIB=.../build/liblanczos_hip_prof.so
+# (the production library contains neither the ablation bits nor the switch; the environment is read once per process)
 # scripts/ablate.sh "<skip values>" [bench args] -- kernel time with phases of the marching kernel switched off
 skips="$1"; shift
 for skip in $skips; do

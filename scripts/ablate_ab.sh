@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# NEEDS the profiling build (-DLZ_PROFILE_BITS); the environment is read once per process: one process per LANCZOS_DEBUG_SKIP value
 # scripts/ablate_ab.sh <config> <patterns> -- phases of the marching kernel switched off (LANCZOS_DEBUG_SKIP bits of a
 # -DLZ_PROFILE_BITS build), all variants interleaved in ONE process: copies of the library under different names so that
 # each gets its own function-local statics.

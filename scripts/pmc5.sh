@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+# NEEDS the profiling build for the skip=8 leg (LANCZOS_LIB=.../build/liblanczos_hip_prof.so)
 # scripts/pmc5.sh: VALU occupancy counters for the full kernel and the no-store ablation (GPU box)
 set -uo pipefail
 export TMPDIR=/tmp
