@@ -8,8 +8,9 @@
 Every library is loaded with its own ctypes handle (same C ABI), gets its own context, and runs `steps` whole steps per
 round on torch's current stream, timed with torch.cuda events (device time of the whole step: every kernel + gaps).
 Prints per library / pattern: median, min and all rounds in us, and the HBM-roofline fraction of the median.
-A library spec may carry environment overrides that are applied while IT is loaded and run: "path.so@LANCZOS_X=1,LANCZOS_Y=2"
-(only for switches the library reads at call time, not those cached in function-local statics).
+Since round 3 the library reads its environment switches ONCE per process (first lanczos_create, csrc/lanczos_env.hpp): set them
+for the whole run (`LANCZOS_X=1 python3 scripts/ab.py ...`), one process per setting.  The "path.so@NAME=V" suffix of a library
+spec is still parsed (it names the variant in the output) but no longer selects behaviour per library.
 """
 import argparse
 import ctypes
