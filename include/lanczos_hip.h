@@ -180,6 +180,12 @@ typedef struct lanczos_xfer {
     size_t src_off, dst_off, bytes;
 } lanczos_xfer;
 int lanczos_multi_exchange_plan(const lanczos_desc* d, int frames, int split, int n_devices, int phase, lanczos_xfer* out, int cap);
+/* What a ONE-GPU machine can execute of the RCCL path: loads librccl, builds a one-rank communicator on the context's first
+ * device and moves `messages` self messages of `bytes` bytes each between two device buffers through the same group executor and
+ * send / recv adapter as lanczos_resample_multi_root; the bytes are compared.  fail_at >= 0 makes message `fail_at` name a peer
+ * that does not exist: the call then returns LANCZOS_ERR_RCCL and lanczos_multi_last_error() names that message (the group is
+ * closed, the communicator proven usable afterwards).  LANCZOS_ERR_UNSUPPORTED: no librccl on this system.  (rccl.h:700,722) */
+int lanczos_multi_exchange_selftest(lanczos_multi* m, int messages, size_t bytes, int fail_at);
 /* Device memory for plain-C callers that do not include the HIP headers (host/main.c --root). */
 int lanczos_device_alloc(int device, void** p, size_t bytes);
 int lanczos_device_free(int device, void* p);

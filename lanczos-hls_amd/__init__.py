@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LANCZOS_LIB: load another build of the same C ABI (A/B experiments); default is the in-tree product build
 LIB_PATH = os.environ.get("LANCZOS_LIB") or os.path.join(_HERE, "liblanczos_hip.so")
 
-OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM = range(6)
+OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_RCCL = range(7)   # include/lanczos_hip.h:43-49
 MODE_LSB1, MODE_EXACT, MODE_HLS = 0, 1, 2
 KERNEL_NONE, KERNEL_GENERIC, KERNEL_FAST, KERNEL_HLS = 0, 1, 2, 3
 
@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "lanczos_version",
     "lanczos_partition_frames", "lanczos_partition_rows", "lanczos_multi_create", "lanczos_multi_destroy",
     "lanczos_multi_devices", "lanczos_resample_multi_host", "lanczos_resample_multi_root",
-    "lanczos_multi_last_error", "lanczos_multi_exchange_plan", "lanczos_device_alloc", "lanczos_device_free",
+    "lanczos_multi_last_error", "lanczos_multi_exchange_plan", "lanczos_multi_exchange_selftest", "lanczos_device_alloc", "lanczos_device_free",
     "lanczos_device_copy",
 ]
 SPLIT_FRAMES, SPLIT_ROWS = 0, 1
@@ -373,6 +373,17 @@ class MultiContext:
         _check(_lib().lanczos_resample_multi_root(self._h, ctypes.byref(desc), d_in_root, d_out_root, frames, split,
                                                   ctypes.byref(cm), ctypes.byref(tm)), "lanczos_resample_multi_root")
         return cm.value, tm.value
+
+
+    def exchange_selftest(self, messages=4, nbytes=1 << 20, fail_at=-1):
+        """The RCCL exchange machinery on one rank (lanczos_multi_exchange_selftest): returns the C status code and, for
+        ERR_RCCL, (rccl_error, message index) from lanczos_multi_last_error."""
+        lib = _lib()
+        lib.lanczos_multi_exchange_selftest.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_int]
+        rc = lib.lanczos_multi_exchange_selftest(self._h, messages, nbytes, fail_at)
+        he, re_, at = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib.lanczos_multi_last_error(self._h, ctypes.byref(he), ctypes.byref(re_), ctypes.byref(at))
+        return rc, re_.value, at.value
 
 
 _default_ctx = None

@@ -41,6 +41,9 @@ struct Plan {
     lz::PrefixInfo prefix;
     lz::TapTables dev{};       // device copies
     void* dev_block = nullptr;  // one allocation behind `dev`
+    void* host_block = nullptr; // page-locked source of the asynchronous upload (alive as long as the plan: a captured graph replays the copy)
+    hipEvent_t uploaded = nullptr;       // recorded behind the upload ...
+    hipStream_t upload_stream = nullptr; // ... on this stream (the stream of the plan's first call)
     lz::FastConsts fast{};      // phase weights etc. for the specialised kernels
     bool fast_ok = false;
     lz::RatHost rat;            // rational scales: per-index f32 weights, integer-phase flags (k_rat)
@@ -56,7 +59,7 @@ struct lanczos_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::map<PlanKey, Plan*> plans;
-    std::vector<PlanKey> plan_order;   // oldest first: the cache is bounded (kMaxPlans), the oldest plan is retired
+    lz::LruOrder<PlanKey> plan_order;  // the cache is bounded (kMaxPlans): the least recently used plan is retired
     lz::RetireList retired_plans;
     std::mutex mu;
     int last_kernel = LANCZOS_KERNEL_NONE;
@@ -101,7 +104,17 @@ namespace {
         }                                                  \
     } while (0)
 
-int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
+void free_plan(Plan* p) {   // nothing in flight reads it any more
+    if (p->dev_block) (void)hipFree(p->dev_block);
+    if (p->host_block) (void)hipHostFree(p->host_block);
+    if (p->uploaded) (void)hipEventDestroy(p->uploaded);
+    delete p;
+}
+
+// The plan of a shape: tap tables built on the host, uploaded ONCE, asynchronously, on the stream of the first call that needs
+// them (page-locked source, no device-wide wait: the entry points stay asynchronous on the caller's stream and can be captured
+// into a graph in relaxed capture mode; calls on other streams wait for the upload by event).
+int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, hipStream_t stream, Plan** out) {
     PlanKey key;
     memset(&key, 0, sizeof(key));
     const bool hls = d->mode == LANCZOS_MODE_HLS;
@@ -109,19 +122,25 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
                   d->scale_n, d->scale_d, d->a, hls ? 1 + d->reserved[0] : 0};
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) {
-        *out = it->second;
+        Plan* p = it->second;
+        ctx->plan_order.touch(key);
+        if (stream != p->upload_stream && hipEventQuery(p->uploaded) != hipSuccess)
+            LZ_HIP(ctx, hipStreamWaitEvent(stream, p->uploaded, 0));  // another stream: behind the upload
+        lz::note_stream(p->streams, stream);
+        *out = p;
         return LANCZOS_OK;
     }
     ctx->retired_plans.reap(false);
-    if (ctx->plans.size() >= kMaxPlans) {
-        // bounded: a caller that cycles through many shapes does not grow device memory without limit.  The oldest plan's
-        // tables are freed once the launches that read them have drained (events on the streams it was used on).
-        const PlanKey old = ctx->plan_order.front();
-        ctx->plan_order.erase(ctx->plan_order.begin());
+    if (ctx->plans.size() >= kMaxPlans && !ctx->plan_order.empty()) {
+        // bounded: a caller that cycles through many shapes does not grow device memory without limit.  The least recently used
+        // plan's tables are freed once the launches that read them have drained (events on the streams it was used on).
+        const PlanKey old = ctx->plan_order.pop_oldest();
         auto io = ctx->plans.find(old);
         if (io != ctx->plans.end()) {
-            ctx->retired_plans.retire({io->second->dev_block}, {}, io->second->streams);
-            delete io->second;
+            Plan* q = io->second;
+            ctx->retired_plans.retire({q->dev_block}, {q->host_block}, q->streams);
+            if (q->uploaded) (void)hipEventDestroy(q->uploaded);
+            delete q;
             ctx->plans.erase(io);
         }
     }
@@ -160,7 +179,17 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
         off_pw = total;
         total += sizeof(p->ratp.phase_w);
     }
-    std::vector<uint8_t> host(total, 0);
+    hipError_t e = hipHostMalloc(&p->host_block, total, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        delete p;
+        return LANCZOS_ERR_HIP;
+    }
+    struct HostView {   // (the sections below were written against a std::vector; same two members)
+        uint8_t* b;
+        uint8_t* data() const { return b; }
+    } host{(uint8_t*)p->host_block};
+    memset(host.data(), 0, total);
     if (p->rat.ok) {
         memcpy(host.data() + off_hwf, p->rat.h_wf.data(), p->rat.h_wf.size() * 4);
         memcpy(host.data() + off_vwf, p->rat.v_wf.data(), p->rat.v_wf.size() * 4);
@@ -177,19 +206,25 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
     memcpy(host.data() + off_vf, p->V.first.data(), (size_t)d->out_h * 4);
     memcpy(host.data() + off_hw, p->H.w.data(), (size_t)d->out_w * taps * 8);
     memcpy(host.data() + off_vw, p->V.w.data(), (size_t)d->out_h * taps * 8);
-    hipError_t e = hipMalloc(&p->dev_block, total);
+    e = hipMalloc(&p->dev_block, total);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming);
     if (e != hipSuccess) {
         ctx->last_hip = (int)e;
+        free_plan(p);
+        return LANCZOS_ERR_HIP;
+    }
+    e = hipMemcpyAsync(p->dev_block, p->host_block, total, hipMemcpyHostToDevice, stream);  // stream-ordered in front of the first launch
+    if (e == hipSuccess) e = hipEventRecord(p->uploaded, stream);
+    if (e != hipSuccess) {
+        // the copy may have been queued: its two blocks go through the retire list, not straight back to the allocator
+        ctx->last_hip = (int)e;
+        ctx->retired_plans.retire({p->dev_block}, {p->host_block}, {stream});
+        if (p->uploaded) (void)hipEventDestroy(p->uploaded);
         delete p;
         return LANCZOS_ERR_HIP;
     }
-    e = hipMemcpy(p->dev_block, host.data(), total, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        ctx->last_hip = (int)e;
-        (void)hipFree(p->dev_block);
-        delete p;
-        return LANCZOS_ERR_HIP;
-    }
+    p->upload_stream = stream;
+    p->streams.push_back(stream);
     uint8_t* b = (uint8_t*)p->dev_block;
     p->dev.h_first = (const int32_t*)(b + off_hf);
     p->dev.v_first = (const int32_t*)(b + off_vf);
@@ -215,7 +250,7 @@ int get_plan(lanczos_ctx* ctx, const lanczos_desc* d, Plan** out) {
         p->ratp_w_dev = (const float*)(b + off_pw);
     }
     ctx->plans[key] = p;
-    ctx->plan_order.push_back(key);
+    ctx->plan_order.touch(key);
     *out = p;
     return LANCZOS_OK;
 }
@@ -459,10 +494,7 @@ int lanczos_destroy(lanczos_ctx* ctx) {
     (void)hipDeviceSynchronize();
     ctx->retired_plans.reap(true);
     ctx->wg_tabs.release_all();
-    for (auto& kv : ctx->plans) {
-        if (kv.second->dev_block) (void)hipFree(kv.second->dev_block);
-        delete kv.second;
-    }
+    for (auto& kv : ctx->plans) free_plan(kv.second);
     ctx->plans.clear();
 #ifdef LZ_PROFILE_BITS
     if (ctx->stamp_buf) {
@@ -559,12 +591,12 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
                                   size_t in_frame_stride, size_t out_frame_stride, void* stream_v, bool in_split = false) {
     int rc;
     LZ_HIP(ctx, hipSetDevice(ctx->device));
-    Plan* p = nullptr;
-    rc = get_plan(ctx, d, &p);
-    if (rc != LANCZOS_OK) return rc;
     // NULL is the NULL (legacy default) stream -- NOT the context's private stream: a caller whose producers run
     // on the default stream (torch's default stream is handle 0) must be ordered behind them
     hipStream_t stream = (hipStream_t)stream_v;
+    Plan* p = nullptr;
+    rc = get_plan(ctx, d, stream, &p);
+    if (rc != LANCZOS_OK) return rc;
 
     int row0, rows;
     whole_or_strip(d, &row0, &rows);
@@ -609,8 +641,6 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
         g.stamps = (unsigned long long*)ctx->stamp_buf;
     }
 #endif
-    lz::note_stream(p->streams, (hipStream_t)stream_v);
-
     if (d->mode == LANCZOS_MODE_HLS) {
         if (ctx->force == LANCZOS_KERNEL_FAST || ctx->force == LANCZOS_KERNEL_GENERIC) return LANCZOS_ERR_UNSUPPORTED;
         if (d->channels > 4 || 2 * d->a > 2 * lz::kMaxA) return LANCZOS_ERR_UNSUPPORTED;
@@ -666,7 +696,7 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
             e = lz::fast_launch(*d, g, p->dev, p->fast, stream);
         } else {
             lz::FrameGeom gm = g;
-            if (!ctx->timing && !in_split) {
+            if (!in_split) {   // (with timing on, every sub-launch commits its own event triple: what is timed is what is shipped)
                 // A batch of twice the kernel's preferred size or more goes out as several launches of that size: one resident
                 // round of workgroups with two chunks per (strip, frame) pair is the fastest shape this kernel has.
                 bool dummy = false;
@@ -816,8 +846,9 @@ int lanczos_resample_host(lanczos_ctx* ctx, const lanczos_desc* d, const void* i
     // for the whole call (calls on one context are serialised; use one context per host thread to overlap them).
     std::lock_guard<std::mutex> lock(ctx->mu);
     LZ_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->stream) return LANCZOS_ERR_HIP;
     Plan* p = nullptr;
-    rc = get_plan(ctx, d, &p);
+    rc = get_plan(ctx, d, ctx->stream, &p);   // (the pipeline's resample calls run on the context's stream)
     if (rc != LANCZOS_OK) return rc;
     int row0, rows, in_row0, in_rows;
     whole_or_strip(d, &row0, &rows);

@@ -47,6 +47,7 @@
 #include <utility>
 #include <vector>
 
+#include "lanczos_cache.hpp"
 #include "lanczos_env.hpp"
 #include "lanczos_fast.hpp"
 
@@ -1176,89 +1177,8 @@ inline int march_build_table(std::vector<WgEntry>& tab, int* segs_out, int strip
     return n;
 }
 
-// Resources that launches still in flight may be reading are not freed on the spot and never with a device-wide sync: an
-// event is recorded on every stream the resource was used on, and the resource is freed by a later call once those events
-// have completed (or at destruction, after waiting for them).
-struct Retired {
-    std::vector<void*> dev, host;   // hipFree / hipHostFree
-    std::vector<hipEvent_t> ev;
-};
-struct RetireList {
-    std::vector<Retired> list;
-    void retire(const std::vector<void*>& dev, const std::vector<void*>& host, const std::vector<hipStream_t>& streams) {
-        Retired r;
-        r.dev = dev;
-        r.host = host;
-        for (hipStream_t st : streams) {
-            hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess && hipEventRecord(e, st) == hipSuccess) r.ev.push_back(e);
-            else if (e) (void)hipEventDestroy(e);
-        }
-        list.push_back(r);
-    }
-    void reap(bool wait) {
-        for (size_t i = 0; i < list.size();) {
-            bool done = true;
-            for (hipEvent_t e : list[i].ev) {
-                if (wait) (void)hipEventSynchronize(e);
-                else if (hipEventQuery(e) != hipSuccess) done = false;
-            }
-            if (!done) {
-                i++;
-                continue;
-            }
-            for (hipEvent_t e : list[i].ev) (void)hipEventDestroy(e);
-            for (void* p : list[i].dev) (void)hipFree(p);
-            for (void* p : list[i].host) (void)hipHostFree(p);
-            list.erase(list.begin() + i);
-        }
-    }
-    ~RetireList() { reap(true); }
-};
-inline void note_stream(std::vector<hipStream_t>& v, hipStream_t s) {
-    if (std::find(v.begin(), v.end(), s) == v.end()) v.push_back(s);
-}
-
-// device copies of the workgroup tables a context has used (callers serialise per context).  A table is built once per launch
-// shape into page-locked memory and uploaded asynchronously on the stream of its first launch; launches on other streams wait
-// for that upload by event.  Bounded: the oldest shape is retired when the 65th arrives.
-struct WgTabCache {
-    struct Item {
-        long long key[8];
-        WgEntry* dev = nullptr;
-        WgEntry* host = nullptr;           // page-locked source of the upload (stays valid while the copy is in flight)
-        int n = 0, segs = 1;
-        bool balanced = false;
-        hipEvent_t uploaded = nullptr;     // recorded behind the upload
-        hipStream_t upload_stream = nullptr;
-        std::vector<hipStream_t> streams;  // streams this shape was launched on
-    };
-    std::vector<Item> items;
-    RetireList retired;
-    // set by every march_launch (query or launch): the batch size this kernel instance runs best at for this frame width -- the
-    // largest one whose (strip, frame) pairs, cut in two chunks each, fill ONE resident round of workgroups with rank-aware
-    // shares (config 2: 32 frames = 960 workgroups on 1 024 slots).  Larger batches are faster as several launches of this size
-    // (64 frames: 2 x 207 us against 502 us in one launch, profiles/round3g_bench_default.json); 0: no preference
-    int pref_frames = 0;
-    void drop(size_t i) {
-        Item& it = items[i];
-        retired.retire({it.dev}, {it.host}, it.streams);
-        if (it.uploaded) (void)hipEventDestroy(it.uploaded);
-        items.erase(items.begin() + i);
-    }
-    // the owner has made sure that nothing is in flight any more (lanczos_destroy: after the device has drained, before the
-    // context's streams go): free everything now -- no events on streams that may be gone by the time a destructor runs
-    void release_all() {
-        retired.reap(true);
-        for (Item& it : items) {
-            (void)hipFree(it.dev);
-            (void)hipHostFree(it.host);
-            if (it.uploaded) (void)hipEventDestroy(it.uploaded);
-        }
-        items.clear();
-    }
-    ~WgTabCache() { release_all(); }
-};
+// retire lists and the table cache: lanczos_cache.hpp (host-only, tested without a GPU)
+using WgTabCache = WgTabCacheT<WgEntry>;
 
 template <typename T, int C, int S, int A>
 inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, const TapTables& t,
@@ -1277,7 +1197,6 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     const int strips = (g.out_w + F::TWP_OUT - 1) / F::TWP_OUT;
     const int y_lo = g.out_row0 > g.skip_rows ? g.out_row0 : g.skip_rows;
     const int y_hi = g.out_row0 + g.out_rows;
-    if (y_lo >= y_hi) return hipSuccess;
     const bool exact = d.mode == LANCZOS_MODE_EXACT;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1320,38 +1239,29 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
         while (pf > 0 && (2 * strips * pf) % 16 != 0) pf--;   // every XCD gets whole pairs of chunks (march_build_table: balanced)
         cache->pref_frames = pf;
     }
+    // Measured (config 2, ms per step riding / separate): 1 frame 0.0198 / 0.0253, 2: 0.0281 / 0.0335, 4: 0.0464 / 0.0525,
+    // 8: 0.0687 / 0.0729, 16: 0.117-0.120 / 0.114-0.116, 32: 0.232 / 0.218 -- past about one prefix workgroup per CU they slow
+    // the march down more than the launch they replace (profiles/round3a_ab_prefix_riding_and_ldsdma_placement.txt).
+    g.prefix_blocks_per_frame = g.prefix_K > 0 ? (g.out_w * C + K::NT - 1) / K::NT : 0;
+    if (g.prefix_blocks_per_frame * g.frames > cus) {
+        g.prefix_K = g.prefix_M = g.prefix_M2 = g.prefix_blocks_per_frame = 0;
+        *prefix_fused = false;
+    }
+    // a pure query (the caller wants *prefix_fused and pref_frames) touches neither the table cache nor the stream
+    if (query_only || y_lo >= y_hi) return hipSuccess;
     // the workgroup table of this launch shape (built once per context and shape)
     const int m_lo = y_lo / S, m_hi = (y_hi - 1) / S + 1;
     const long long key[8] = {(long long)sizeof(T) | ((long long)C << 8) | ((long long)S << 16) | ((long long)A << 24) | ((long long)exact << 32),
                               strips, g.frames, m_lo, m_hi, nb, cus, dev};
-    WgTabCache::Item* item = nullptr;
-    for (auto& it : cache->items)
-        if (memcmp(it.key, key, sizeof(key)) == 0) item = &it;
+    WgTabCache::Item* item = cache->find(key);
     if (!item) {
-        cache->retired.reap(false);
         std::vector<WgEntry> tab;
-        WgTabCache::Item it;
-        memcpy(it.key, key, sizeof(key));
-        it.n = march_build_table(tab, &it.segs, strips, g.frames, m_lo, m_hi, K::MS, K::TAPS, nb, cus, K::NWAVES, &it.balanced);
-        const size_t bytes = sizeof(WgEntry) * tab.size();
-        hipError_t e = hipMalloc(&it.dev, bytes);
-        if (e == hipSuccess) e = hipHostMalloc((void**)&it.host, bytes, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&it.uploaded, hipEventDisableTiming);
-        if (e == hipSuccess) {
-            memcpy(it.host, tab.data(), bytes);
-            e = hipMemcpyAsync(it.dev, it.host, bytes, hipMemcpyHostToDevice, stream);  // stream-ordered in front of the first launch
-        }
-        if (e == hipSuccess) e = hipEventRecord(it.uploaded, stream);
-        if (e != hipSuccess) {
-            if (it.dev) (void)hipFree(it.dev);
-            if (it.host) (void)hipHostFree(it.host);
-            if (it.uploaded) (void)hipEventDestroy(it.uploaded);
-            return e;
-        }
-        it.upload_stream = stream;
-        if (cache->items.size() >= 64) cache->drop(0);  // bounded: the oldest shape goes (freed once its launches have drained)
-        cache->items.push_back(it);
-        item = &cache->items.back();
+        int segs = 1;
+        bool balanced = false;
+        const int n = march_build_table(tab, &segs, strips, g.frames, m_lo, m_hi, K::MS, K::TAPS, nb, cus, K::NWAVES, &balanced);
+        hipError_t e = hipSuccess;
+        item = cache->insert(key, tab, n, segs, balanced, stream, &e);
+        if (!item) return e;
         if (env().verbose)
             fprintf(stderr, "lanczos: k_march table: %d workgroups x %d segment(s) for %d strips x %d frames, rows [%d, %d): %s shares\n", item->n,
                     item->segs, strips, g.frames, m_lo, m_hi, item->balanced ? "rank-aware" : "equal");
@@ -1364,15 +1274,6 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     g.wg_segs = item->segs;
     g.wg_per_frame = 0;
     g.n_main = item->n;
-    g.prefix_blocks_per_frame = g.prefix_K > 0 ? (g.out_w * C + K::NT - 1) / K::NT : 0;
-    // Measured (config 2, ms per step riding / separate): 1 frame 0.0198 / 0.0253, 2: 0.0281 / 0.0335, 4: 0.0464 / 0.0525,
-    // 8: 0.0687 / 0.0729, 16: 0.117-0.120 / 0.114-0.116, 32: 0.232 / 0.218 -- past about one prefix workgroup per CU they slow
-    // the march down more than the launch they replace (profiles/round3a_ab_prefix_riding_and_ldsdma_placement.txt).
-    if (g.prefix_blocks_per_frame * g.frames > cus) {
-        g.prefix_K = g.prefix_M = g.prefix_M2 = g.prefix_blocks_per_frame = 0;
-        *prefix_fused = false;
-    }
-    if (query_only) return hipSuccess;  // the caller only wanted *prefix_fused (it launches the prefix rows itself, first)
     note_stream(item->streams, stream);
     dim3 grid(g.n_main + g.prefix_blocks_per_frame * g.frames);
     if (*prefix_fused) {
@@ -1392,7 +1293,6 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     return hipGetLastError();
 }
 
-struct WgTabCache;
 #define LZ_DECLARE_MARCH_GROUP(G)                                                                                                  \
     hipError_t march_launch_g##G(const lanczos_desc& d, const FrameGeom& g, const TapTables& t, const FastConsts& fc, hipStream_t stream, \
                                  bool* prefix_fused, WgTabCache* cache, bool query_only);

@@ -13,6 +13,7 @@
 //     loaded on first use (dlopen), so single-GPU users never touch it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: nothing of librccl is linked (see Rccl below)
 
 #include <cstdio>
 #include <cstring>
@@ -36,24 +37,23 @@ struct DeviceGuard {
     }
 };
 
-// ---- the slice of rccl.h this file uses (declared here so that the library has no link-time dependency on librccl)
-typedef struct ncclComm* ncclComm_t;
-typedef int ncclResult_t;
-enum { kNcclUint8 = 1 };
+// ---- RCCL: types and signatures come from the installed header (a drift between it and the calls below is a compile error,
+// not a crash at a customer's 8-GPU node); the symbols are still looked up at run time (dlopen on first use), so the library has
+// no link-time dependency on librccl and single-GPU users never load it.
 struct Rccl {
     void* lib = nullptr;
-    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     bool load() {
         if (lib) return true;
-        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) return false;
-#define SYM(field, name) *(void**)(&field) = dlsym(lib, name)
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return false;
+#define SYM(field, name) *(void**)(&field) = dlsym(h, name)
         SYM(CommInitAll, "ncclCommInitAll");
         SYM(CommDestroy, "ncclCommDestroy");
         SYM(GroupStart, "ncclGroupStart");
@@ -61,7 +61,32 @@ struct Rccl {
         SYM(Send, "ncclSend");
         SYM(Recv, "ncclRecv");
 #undef SYM
-        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+        if (!(CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv)) {
+            // a library without one of the six: not loaded (a second call must not find `lib` set and null pointers behind it)
+            CommInitAll = nullptr, CommDestroy = nullptr, GroupStart = nullptr, GroupEnd = nullptr, Send = nullptr, Recv = nullptr;
+            dlclose(h);
+            return false;
+        }
+        lib = h;
+        return true;
+    }
+};
+
+// One message list = one RCCL group (lz::exchange_run).  Rank r sends from send_base[r] and receives into recv_base[r] on its own
+// communicator and stream.
+struct RootOps {
+    Rccl* rccl;
+    const std::vector<ncclComm_t>* comms;
+    const std::vector<hipStream_t>* streams;
+    std::vector<const uint8_t*> send_base;
+    std::vector<uint8_t*> recv_base;
+    int group_start() { return (int)rccl->GroupStart(); }
+    int group_end() { return (int)rccl->GroupEnd(); }
+    int send(int rank, size_t off, size_t bytes, int peer) {
+        return (int)rccl->Send(send_base[rank] + off, bytes, ncclUint8, peer, (*comms)[rank], (*streams)[rank]);
+    }
+    int recv(int rank, size_t off, size_t bytes, int peer) {
+        return (int)rccl->Recv(recv_base[rank] + off, bytes, ncclUint8, peer, (*comms)[rank], (*streams)[rank]);
     }
 };
 
@@ -301,7 +326,7 @@ int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const v
     if (n > 1 && m->comms.empty()) {
         if (!m->rccl.load()) return LANCZOS_ERR_UNSUPPORTED;  // no librccl on this system
         m->comms.assign(n, nullptr);
-        const int r = m->rccl.CommInitAll(m->comms.data(), n, m->devices.data());
+        const int r = (int)m->rccl.CommInitAll(m->comms.data(), n, m->devices.data());
         if (r != 0) {
             m->comms.clear();
             m->last_rccl = r;
@@ -343,28 +368,16 @@ int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const v
         }
         return LANCZOS_OK;
     };
-    // one list = one RCCL group; rank r's buffer: the root's caller buffers (r == 0) or the peer's shard buffer
-    struct Ops {
-        lanczos_multi* m;
-        const uint8_t* root_src;   // what rank 0 sends from
-        uint8_t* root_dst;         // what rank 0 receives into
-        bool scatter;
-        int group_start() { return m->rccl.GroupStart(); }
-        int group_end() { return m->rccl.GroupEnd(); }
-        int send(int rank, size_t off, size_t bytes, int peer) {
-            const uint8_t* base = rank == 0 ? root_src : (const uint8_t*)(scatter ? m->d_in[rank] : m->d_out[rank]);
-            return m->rccl.Send(base + off, bytes, kNcclUint8, peer, m->comms[rank], m->streams[rank]);
-        }
-        int recv(int rank, size_t off, size_t bytes, int peer) {
-            uint8_t* base = rank == 0 ? root_dst : (uint8_t*)(scatter ? m->d_in[rank] : m->d_out[rank]);
-            return m->rccl.Recv(base + off, bytes, kNcclUint8, peer, m->comms[rank], m->streams[rank]);
-        }
-    };
     auto exchange = [&](bool scatter) -> int {
         std::vector<lz::ExXfer> list;
         if (scatter) lz::exchange_scatter_plan(geo, sh, &list);
         else lz::exchange_gather_plan(geo, sh, &list);
-        Ops ops{m, (const uint8_t*)d_in_root, (uint8_t*)d_out_root, scatter};
+        // rank r's buffer: the root's caller buffers (r == 0) or the peer's shard buffer
+        RootOps ops{&m->rccl, &m->comms, &m->streams, {}, {}};
+        for (int r = 0; r < n; r++) {
+            ops.send_base.push_back(r == 0 ? (const uint8_t*)d_in_root : (const uint8_t*)(scatter ? m->d_in[r] : m->d_out[r]));
+            ops.recv_base.push_back(r == 0 ? (uint8_t*)d_out_root : (uint8_t*)(scatter ? m->d_in[r] : m->d_out[r]));
+        }
         int at = 0;
         const int r = lz::exchange_run(ops, list, &at);
         if (r != 0) {
@@ -410,6 +423,82 @@ int lanczos_resample_multi_root(lanczos_multi* m, const lanczos_desc* d, const v
     if (compute_ms) *compute_ms = t_c1 - t_c0;
     if (total_ms) *total_ms = now_ms() - t_start;
     return LANCZOS_OK;
+}
+
+// The exchange machinery of lanczos_resample_multi_root on ONE rank: librccl loaded (dlopen + the six symbols), a one-device
+// communicator (ncclCommInitAll on devices[0]), and `messages` self messages (rank 0 -> rank 0, `bytes` each) issued through the
+// SAME executor and adapter as the real exchange (lz::exchange_run, RootOps) from one device buffer into another; the bytes are
+// compared afterwards.  fail_at >= 0: message `fail_at` names a peer that does not exist -- the call must come back as
+// LANCZOS_ERR_RCCL with lanczos_multi_last_error() naming that message, the group closed, the communicator still usable.
+// This is what a one-GPU box can execute of the RCCL path (the multi-rank exchange itself needs a multi-GPU node).
+int lanczos_multi_exchange_selftest(lanczos_multi* m, int messages, size_t bytes, int fail_at) {
+    if (!m || messages < 1 || messages > 1024 || bytes == 0 || bytes > ((size_t)1 << 28) || fail_at >= messages) return LANCZOS_ERR_BAD_ARG;
+    DeviceGuard restore;
+    m->last_hip = m->last_rccl = m->last_rccl_at = 0;
+    if (!m->rccl.load()) return LANCZOS_ERR_UNSUPPORTED;  // no librccl on this system
+    const int dev = m->devices[0];
+    LZM_HIP(hipSetDevice(dev));
+    std::vector<ncclComm_t> comm(1, nullptr);
+    std::vector<hipStream_t> stream(1, nullptr);
+    uint8_t *a = nullptr, *b = nullptr;
+    std::vector<uint8_t> ha(bytes * messages), hb(bytes * messages, 0);
+    for (size_t i = 0; i < ha.size(); i++) ha[i] = (uint8_t)(i * 2654435761u >> 13);
+    int rc = LANCZOS_OK;
+    auto cleanup = [&]() {
+        if (stream[0]) (void)hipStreamSynchronize(stream[0]);
+        if (comm[0]) (void)m->rccl.CommDestroy(comm[0]);
+        if (a) (void)hipFree(a);
+        if (b) (void)hipFree(b);
+        if (stream[0]) (void)hipStreamDestroy(stream[0]);
+    };
+    hipError_t he = hipStreamCreateWithFlags(&stream[0], hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipMalloc((void**)&a, ha.size());
+    if (he == hipSuccess) he = hipMalloc((void**)&b, hb.size());
+    if (he == hipSuccess) he = hipMemcpy(a, ha.data(), ha.size(), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemset(b, 0, hb.size());
+    if (he != hipSuccess) {
+        m->last_hip = (int)he;
+        cleanup();
+        return LANCZOS_ERR_HIP;
+    }
+    const int ri = (int)m->rccl.CommInitAll(comm.data(), 1, &dev);
+    if (ri != 0) {
+        comm[0] = nullptr;
+        m->last_rccl = ri;
+        m->last_rccl_at = -1;
+        cleanup();
+        return LANCZOS_ERR_RCCL;
+    }
+    std::vector<lz::ExXfer> list;
+    for (int k = 0; k < messages; k++)  // reversed placement: message k lands in slot messages-1-k
+        list.push_back(lz::ExXfer{0, k == fail_at ? 5 : 0, (size_t)k * bytes, (size_t)(messages - 1 - k) * bytes, bytes});
+    RootOps ops{&m->rccl, &comm, &stream, {a, a, a, a, a, a}, {b, b, b, b, b, b}};  // (ranks up to 5: the failing message's "peer")
+    int at = 0;
+    const int r = lz::exchange_run(ops, list, &at);
+    he = hipStreamSynchronize(stream[0]);
+    if (r != 0) {
+        m->last_rccl = r;
+        m->last_rccl_at = at;
+        rc = LANCZOS_ERR_RCCL;
+        // the group was closed by exchange_run: the communicator must still work -- one more, clean, message
+        std::vector<lz::ExXfer> one(1, lz::ExXfer{0, 0, 0, 0, bytes});
+        int at2 = 0;
+        if (lz::exchange_run(ops, one, &at2) != 0 || hipStreamSynchronize(stream[0]) != hipSuccess) rc = LANCZOS_ERR_HIP;
+    } else if (he != hipSuccess) {
+        m->last_hip = (int)he;
+        rc = LANCZOS_ERR_HIP;
+    } else {
+        he = hipMemcpy(hb.data(), b, hb.size(), hipMemcpyDeviceToHost);
+        if (he != hipSuccess) {
+            m->last_hip = (int)he;
+            rc = LANCZOS_ERR_HIP;
+        } else {
+            for (int k = 0; k < messages && rc == LANCZOS_OK; k++)
+                if (memcmp(hb.data() + (size_t)(messages - 1 - k) * bytes, ha.data() + (size_t)k * bytes, bytes) != 0) rc = LANCZOS_ERR_HIP;
+        }
+    }
+    cleanup();
+    return rc;
 }
 
 // ---- plain-C callers without the HIP headers (host/main.c --root): device memory on a chosen device

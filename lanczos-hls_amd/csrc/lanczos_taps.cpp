@@ -104,6 +104,8 @@ int validate(const lanczos_desc* d) {
     // reserved[0] = BIT_PRECISION of the HLS mode's fixed-point emulation: 0 (ideal arithmetic) .. 20, 8-bit samples only
     if (d->reserved[0] < 0 || d->reserved[0] > 20) return LANCZOS_ERR_BAD_ARG;
     if (d->reserved[0] > 0 && (d->mode != LANCZOS_MODE_HLS || d->bytes_per_sample != 1)) return LANCZOS_ERR_BAD_ARG;
+    // reserved[1..2] must be 0 (a descriptor built by hand has to be zero-initialised: later versions give these fields a meaning)
+    if (d->reserved[1] != 0 || d->reserved[2] != 0) return LANCZOS_ERR_BAD_ARG;
     // the harness rejects images whose size is not the compiled-in one (full_TB.h:115-118);
     // here: the output must be the input scaled by N/D (integer division, as OUT_WIDTH = IN_WIDTH*3)
     if ((long long)d->in_w * d->scale_n / d->scale_d != d->out_w) return LANCZOS_ERR_BAD_ARG;

@@ -9,7 +9,8 @@
 // Compile-time parameters come from the same macros the reference's params.h defines (lanczos.h:9-31):
 //   IN_WIDTH IN_HEIGHT OUT_WIDTH OUT_HEIGHT NUM_CHANNELS LANCZOS_A
 // Unlike the reference (globals c, r, `static pos`: single shot, lanczos.cpp:17-18,54) this lanczos() can be
-// called repeatedly.
+// called repeatedly, and from several threads.  Also here: the kernel.h call surface (kernel.h:2-8) --
+// lanczos_kernel(input_idx_t, output_idx_t, scale_t) and raw_lanczos_kernel(kernel_t).
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -50,9 +51,50 @@ struct lz_packed {  // stands where the reference has `typedef ap_uint<8*NUM_CHA
 typedef lz_packed<NUM_CHANNELS> byte_t;
 typedef hls::stream<byte_t>& stream_t;  // lanczos.h:121
 
+// SCALE_N / SCALE_D: the reference reduces OUT_WIDTH / IN_WIDTH by their gcd (lanczos.h:108-114); params.h may also name them
+constexpr int lz_compat_gcd(int a, int b) { return b == 0 ? a : lz_compat_gcd(b, a % b); }
+#ifndef SCALE_N
+#define SCALE_N (OUT_WIDTH / lz_compat_gcd(OUT_WIDTH, IN_WIDTH))
+#endif
+#ifndef SCALE_D
+#define SCALE_D (IN_WIDTH / lz_compat_gcd(OUT_WIDTH, IN_WIDTH))
+#endif
+
+// ---- kernel.h:2-8.  The reference's kernel_t is ap_fixed<8+BIT_PRECISION,8>; here the weights are the software twin's doubles
+// (full_TB.h:51-53), which is what the resample itself uses.
+typedef int input_idx_t;
+typedef int output_idx_t;
+typedef float scale_t;
+typedef double kernel_t;
+// kernel.cpp:12-18: a/pi^2 * sinpi(x) * sinpi(x/a) / x^2, 1 at 0 -- the Lanczos window L(x) itself
+inline kernel_t raw_lanczos_kernel(kernel_t x) { return ::lanczos_kernel((double)x, LANCZOS_A); }
+// kernel.cpp:50-67: the weight of input sample `in_idx` for output sample `out_idx`, i.e. the ROM entry |out*SCALE_D - in*SCALE_N|
+// (= L at that distance / SCALE_N); like the reference's, this ignores `scale` and reads SCALE_N / SCALE_D
+inline kernel_t lanczos_kernel(input_idx_t in_idx, output_idx_t out_idx, scale_t /*scale*/) {
+    return lanczos_kernel_idx(in_idx, out_idx, SCALE_N, SCALE_D, LANCZOS_A);
+}
+
+// the adapter's context: created on first use (C++11: a function-local static is initialised exactly once, also under concurrent
+// first calls), destroyed when the program ends
+struct lz_compat_context {
+    lanczos_ctx* ctx = nullptr;
+    lz_compat_context() {
+        if (lanczos_create(&ctx, 0) != LANCZOS_OK) ctx = nullptr;
+    }
+    ~lz_compat_context() {
+        if (ctx) lanczos_destroy(ctx);
+    }
+    lz_compat_context(const lz_compat_context&) = delete;
+    lz_compat_context& operator=(const lz_compat_context&) = delete;
+};
+inline lanczos_ctx* lz_compat_ctx() {
+    static lz_compat_context holder;
+    return holder.ctx;
+}
+
 inline void lanczos(stream_t streamin, stream_t streamout) {
-    static lanczos_ctx* ctx = nullptr;
-    if (!ctx && lanczos_create(&ctx, 0) != LANCZOS_OK) {
+    lanczos_ctx* ctx = lz_compat_ctx();   // (calls on it are serialised by the library)
+    if (!ctx) {
         std::fprintf(stderr, "lanczos(): no HIP device\n");
         std::abort();  // the reference's lanczos() is void: no error path
     }

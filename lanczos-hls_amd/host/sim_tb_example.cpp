@@ -68,6 +68,11 @@ int main(int argc, char* argv[]) {
         err += (double)diff * diff;
     }
     printf("RMS err: %.3f\n", sqrt(err / (double)ob.size()));
+    // kernel.h:2-8 as the reference declares it: the weight of input sample 0 for output sample 1 (distance 1/SCALE) through both
+    // entry points, and the window at a whole pixel (sin(pi) in double: ~1e-17, not 0 -- SURVEY.md Q4)
+    printf("lanczos_kernel(0, 1, %g) = %.17g raw_lanczos_kernel(%g) = %.17g raw_lanczos_kernel(1) = %.3g\n", (double)SCALE_N / SCALE_D,
+           (double)lanczos_kernel((input_idx_t)0, (output_idx_t)1, (scale_t)((double)SCALE_N / SCALE_D)), (double)SCALE_D / SCALE_N,
+           (double)raw_lanczos_kernel((kernel_t)((double)SCALE_D / SCALE_N)), (double)raw_lanczos_kernel((kernel_t)1.0));
     char name[160];
     const std::string dir = argv[2];
     snprintf(name, sizeof(name), "%dx%d->%dx%d_%d|%d_%d-", IN_WIDTH, IN_HEIGHT, OUT_WIDTH, OUT_HEIGHT, SCALE_N, SCALE_D, LANCZOS_A);

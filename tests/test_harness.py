@@ -75,6 +75,14 @@ def test_harness_config1_end_to_end(tmp_path):
     diff = np.abs(observed.astype(int) - want.astype(int))
     assert observed.shape == want.shape and diff.max() <= 1
     assert abs(rms - float(np.sqrt((diff.astype(float) ** 2).mean()))) < 1e-3
+    # the kernel.h call surface of hls_compat.hpp (kernel.h:2-8): lanczos_kernel(in, out, scale) and raw_lanczos_kernel(x) give the
+    # software twin's double (full_TB.h:51-53), bit for bit
+    import re
+    m = re.search(r"lanczos_kernel\(0, 1, 2\) = (\S+) raw_lanczos_kernel\(0\.5\) = (\S+) raw_lanczos_kernel\(1\) = (\S+)", r.stdout)
+    assert m, r.stdout
+    want_k = O.lib().oracle_lanczos_kernel(0.5, 2)
+    assert float(m.group(1)) == want_k and float(m.group(2)) == want_k
+    assert 0 < abs(float(m.group(3))) < 1e-15          # sin(pi) in double is not 0
 
 
 @pytest.mark.gpu

