@@ -42,7 +42,7 @@ extern "C" {
 
 #define LANCZOS_OK 0
 #define LANCZOS_ERR_BAD_ARG 1      /* null pointer, non-positive size, out != in*N/D, a or channels unsupported */
-#define LANCZOS_ERR_UNSUPPORTED 2  /* valid request this build cannot run (scale < 1, in-place prefix deeper than 1024 rows) */
+#define LANCZOS_ERR_UNSUPPORTED 2  /* valid request this build cannot run (scale < 1; a row strip that starts inside the in-place prefix rows) */
 #define LANCZOS_ERR_NO_DEVICE 3    /* no HIP device / device index out of range */
 #define LANCZOS_ERR_HIP 4          /* a HIP runtime call failed; see lanczos_last_hip_error() */
 #define LANCZOS_ERR_NOMEM 5
@@ -75,7 +75,7 @@ typedef struct lanczos_desc {
     int32_t out_w, out_h;       /* OUT_WIDTH, OUT_HEIGHT (pixels, FULL frame) = in * N / D         */
     int32_t channels;           /* NUM_CHANNELS: 1, 3 or 4, interleaved                            */
     int32_t bytes_per_sample;   /* 1 (u8, the reference) or 2 (u16 generalisation, clamp 65535)    */
-    int32_t scale_n, scale_d;   /* SCALE_N / SCALE_D >= 1 (1/1: frames up to 1024 rows) */
+    int32_t scale_n, scale_d;   /* SCALE_N / SCALE_D >= 1 (1/1 included: DESIGN.md 1) */
     int32_t a;                  /* LANCZOS_A: 2, 3 or 4                                            */
     int32_t mode;               /* LANCZOS_MODE_*                                                  */
     /* Row strip of the frame to produce (multi-GPU tile sharding).  out_rows == 0 means the whole

@@ -281,13 +281,19 @@ void strip_input_rows(const lz::AxisTaps& V, int a, int in_h, int row0, int rows
 
 extern "C" {
 
-const char* lanczos_version(void) { return "lanczos-hls_amd 0.1 (gfx950)"; }
+const char* lanczos_version(void) {
+#ifdef LZ_PROFILE_BITS
+    return "lanczos-hls_amd 0.1 (gfx950) +profile-bits";   // diagnostic build: ablation bits, stamps (scripts/ablate*.sh check for this)
+#else
+    return "lanczos-hls_amd 0.1 (gfx950)";
+#endif
+}
 
 const char* lanczos_strerror(int code) {
     switch (code) {
         case LANCZOS_OK: return "ok";
         case LANCZOS_ERR_BAD_ARG: return "bad argument (null pointer, size, channels, a, or out != in*N/D)";
-        case LANCZOS_ERR_UNSUPPORTED: return "unsupported configuration (scale < 1 or in-place prefix too deep)";
+        case LANCZOS_ERR_UNSUPPORTED: return "unsupported configuration (scale < 1, or a strip that cuts the in-place prefix rows)";
         case LANCZOS_ERR_NO_DEVICE: return "no HIP device";
         case LANCZOS_ERR_HIP: return "HIP runtime error";
         case LANCZOS_ERR_NOMEM: return "out of memory";
@@ -606,8 +612,7 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
     if (has_prefix) {
         // the prefix recurrence needs rows [0,M) of the output and [0,M2) of the H pass in one place
         if (row0 != 0) return LANCZOS_ERR_UNSUPPORTED;
-        if (p->prefix.M > lz::kMaxPrefixRows || p->prefix.M2 > lz::kMaxPrefixRows + lz::kMaxTaps)
-            return LANCZOS_ERR_UNSUPPORTED;
+        // (any depth runs: prefixes too deep for k_prefix's row arrays take the streaming form of the recurrence, k_prefix_stream)
     }
 
     lz::FrameGeom g{};
@@ -788,9 +793,23 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
         const int samples_w = d->out_w * d->channels;
         // columns per block: the row arrays (M + M2 rows) must fit 60 KB of LDS; deep prefixes (scales close to 1) get fewer
         int bw = 128;
-        while (bw > 8 && (size_t)(p->prefix.M + p->prefix.M2) * bw * d->bytes_per_sample > 60 * 1024) bw >>= 1;
-        if ((size_t)(p->prefix.M + p->prefix.M2) * bw * d->bytes_per_sample > 60 * 1024) return LANCZOS_ERR_UNSUPPORTED;
+        while (bw > 32 && (size_t)(p->prefix.M + p->prefix.M2) * bw * d->bytes_per_sample > 60 * 1024) bw >>= 1;
+        const bool streamed = (size_t)(p->prefix.M + p->prefix.M2) * bw * d->bytes_per_sample > 60 * 1024;
+        if (streamed) bw = 128;   // deep prefix (S = 1: the whole frame; S -> 1): rings of 24 rows instead of M + M2 row arrays
         dim3 grid((samples_w + bw - 1) / bw, frames);
+#define LZ_PREFIX_STREAM(T, TAPS) \
+    hipLaunchKernelGGL((lz::k_prefix_stream<T, TAPS>), grid, dim3(128), 0, stream, g, p->dev, p->prefix.K, p->prefix.M)
+        if (streamed) {
+            if (d->bytes_per_sample == 1) {
+                if (d->a == 2) LZ_PREFIX_STREAM(uint8_t, 4);
+                else if (d->a == 3) LZ_PREFIX_STREAM(uint8_t, 6);
+                else LZ_PREFIX_STREAM(uint8_t, 8);
+            } else {
+                if (d->a == 2) LZ_PREFIX_STREAM(uint16_t, 4);
+                else if (d->a == 3) LZ_PREFIX_STREAM(uint16_t, 6);
+                else LZ_PREFIX_STREAM(uint16_t, 8);
+            }
+        } else
 #define LZ_PREFIX(T, TAPS)                                                                                       \
     hipLaunchKernelGGL((lz::k_prefix<T, TAPS>), grid, dim3(bw), (size_t)(p->prefix.M + p->prefix.M2) * bw * sizeof(T), stream, g, \
                        p->dev, p->prefix.K, p->prefix.M, p->prefix.M2)
@@ -804,6 +823,7 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
             else LZ_PREFIX(uint16_t, 8);
         }
 #undef LZ_PREFIX
+#undef LZ_PREFIX_STREAM
         LZ_HIP(ctx, hipGetLastError());
     }
     if (ev2) {

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kGenTileW) void k_generic(FrameGeom g, TapTables t)
 }
 
 // One thread per (frame, sample column): output rows [0, K) of the in-place vertical pass.
-// pi.M / pi.M2 <= kMaxPrefixRows + kMaxTaps are checked on the host.  TAPS is a template parameter so the
+// The host launches it where (M + M2) rows of 32..128 columns fit 60 KB of LDS (deeper prefixes: k_prefix_stream below).  TAPS is a template parameter so the
 // tap loops unroll and the H-pass loads of a row are all in flight together.
 template <typename T, int TAPS>
 __global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K, int M, int M2) {  // blockDim.x <= 128
@@ -162,6 +162,84 @@ __global__ __launch_bounds__(128) void k_prefix(FrameGeom g, TapTables t, int K,
         if (xx < g.out_row0 || xx >= g.out_row0 + g.out_rows) continue;
         T* orow = (T*)(out_f + (size_t)(xx - g.out_row0) * g.out_pitch);
         orow[j] = os[xx * bw + tl];
+    }
+}
+
+// ---- the same rows at ANY depth: the recurrence as a stream ---------------------------------------------------------------
+// k_prefix keeps every H row and every written row of its column in LDS ([M2 + M][bw]), which caps the depth of the in-place
+// prefix (S = 1: the whole frame height; S -> 1: K ~ a * S / (S - 1) rows).  But full_TB.h:67-77 walks xx downwards and row xx
+// only ever reads
+//   * H rows first(xx) .. first(xx) + 2a - 1 (those <= xx), and first(xx) = floor(xx / S) - a + 1 never increases as xx falls;
+//   * written rows i in (xx, xx + a]   (first + 2a - 1 = floor(xx / S) + a <= xx + a),
+// so a ring of 16 H rows (the 2a-row window + a chunk of 8 rows computed ahead, all their loads in flight together) and a ring
+// of 8 written rows per column carry the whole recurrence: 24 rows of LDS whatever M is.  Rows < K are stored as they appear.
+template <typename T, int TAPS>
+__global__ __launch_bounds__(128) void k_prefix_stream(FrameGeom g, TapTables t, int K, int M) {  // blockDim.x == 128
+    constexpr int HR = 16, OR = 8, CH = 8;
+    static_assert(TAPS <= 8 && CH + TAPS - 1 <= HR && TAPS / 2 + 1 <= OR, "ring sizes");
+    const int C = g.channels;
+    const int samples_w = g.out_w * C;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int frame = blockIdx.y;
+    if (j >= samples_w) return;
+    const uint8_t* in_f = g.in + (size_t)frame * g.in_frame_stride;
+    uint8_t* out_f = g.out + (size_t)frame * g.out_frame_stride;
+    __shared__ T hs[HR][128];   // H row r at [r & 15]
+    __shared__ T os[OR][128];   // written row i at [i & 7]
+    const int tl = threadIdx.x;
+    const int xx_h = j / C, c = j - xx_h * C;
+    int idx[TAPS];
+    double w[TAPS];
+    {
+        const int first = t.h_first[xx_h];
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) {
+            int i = first + k;
+            i = i < 0 ? 0 : (i > g.in_w - 1 ? g.in_w - 1 : i);  // weight is 0 there
+            idx[k] = i * C + c;
+            w[k] = t.h_w[(size_t)xx_h * TAPS + k];
+        }
+    }
+    auto vfirst = [&](int xx) { return t.v_first[xx]; };
+    int h_lo = vfirst(M - 1) + TAPS;            // H rows [h_lo, ...) of the window are in the ring (none yet)
+    if (h_lo > g.in_h) h_lo = g.in_h;
+    for (int xx = M - 1; xx >= 0; xx--) {
+        const int first = vfirst(xx);
+        const int need = first < 0 ? 0 : first;
+        while (h_lo > need) {                    // (uniform per column only -- every thread walks its own column; no barriers)
+            const int r0 = h_lo - CH < 0 ? 0 : h_lo - CH;
+            T v[CH][TAPS];
+#pragma unroll
+            for (int rr = 0; rr < CH; rr++) {    // horizontal pass of a chunk of rows (full_TB.h:55-65): all loads in flight
+                const int r = r0 + rr < h_lo ? r0 + rr : h_lo - 1;
+                const T* row = (const T*)(in_f + (size_t)(r - g.in_row0) * g.in_pitch);
+#pragma unroll
+                for (int k = 0; k < TAPS; k++) v[rr][k] = row[idx[k]];
+            }
+#pragma unroll
+            for (int rr = 0; rr < CH; rr++) {
+                if (r0 + rr >= h_lo) break;
+                double sum = 0;
+#pragma unroll
+                for (int k = 0; k < TAPS; k++) sum += (double)v[rr][k] * w[k];
+                hs[(r0 + rr) & (HR - 1)][tl] = store_convert<T>(sum);
+            }
+            h_lo = r0;
+        }
+        // full_TB.h:69-76: a tap at row i > xx sees the value already written there
+        const double* wv = t.v_w + (size_t)xx * TAPS;
+        double sum = 0;
+#pragma unroll
+        for (int k = 0; k < TAPS; k++) {
+            int i = first + k;
+            i = i < 0 ? 0 : (i > g.in_h - 1 ? g.in_h - 1 : i);  // weight 0 outside
+            const T v = i > xx ? os[i & (OR - 1)][tl] : hs[i & (HR - 1)][tl];
+            sum += (double)v * wv[k];
+        }
+        const T o = store_convert<T>(sum);
+        os[xx & (OR - 1)][tl] = o;
+        if (xx < K && xx >= g.out_row0 && xx < g.out_row0 + g.out_rows)
+            ((T*)(out_f + (size_t)(xx - g.out_row0) * g.out_pitch))[j] = o;
     }
 }
 

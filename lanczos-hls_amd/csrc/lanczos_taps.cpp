@@ -117,7 +117,7 @@ int validate(const lanczos_desc* d) {
     // S < 1: the reference itself is out of bounds there (full_TB.h:85 writes img_out[j][i] for i < IN_HEIGHT into an array of
     // OUT_HEIGHT rows).  S == 1 is well defined -- every sample sits on an integer phase and the in-place vertical pass
     // (full_TB.h:67-77) is ONE recurrence over the whole frame height per column -- and runs wherever that recurrence fits the
-    // in-place-prefix kernel (frames up to kMaxPrefixRows rows; deeper ones: LANCZOS_ERR_UNSUPPORTED from the resample call).
+    // in-place-prefix kernels at any frame height (k_prefix / k_prefix_stream).
     if (d->scale_n < d->scale_d) return LANCZOS_ERR_UNSUPPORTED;
     return LANCZOS_OK;
 }

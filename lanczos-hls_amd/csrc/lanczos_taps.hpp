@@ -15,7 +15,6 @@ namespace lz {
 
 constexpr int kMaxA = 4;
 constexpr int kMaxTaps = 2 * kMaxA;
-constexpr int kMaxPrefixRows = 1024;  // deepest in-place prefix (rows that read written rows) we run: scales down to ~1.003
 
 // full_TB.h:39-44 and :51-53
 double sinc(double x);

@@ -9,8 +9,8 @@ Every library is loaded with its own ctypes handle (same C ABI), gets its own co
 round on torch's current stream, timed with torch.cuda events (device time of the whole step: every kernel + gaps).
 Prints per library / pattern: median, min and all rounds in us, and the HBM-roofline fraction of the median.
 Since round 3 the library reads its environment switches ONCE per process (first lanczos_create, csrc/lanczos_env.hpp): set them
-for the whole run (`LANCZOS_X=1 python3 scripts/ab.py ...`), one process per setting.  The "path.so@NAME=V" suffix of a library
-spec is still parsed (it names the variant in the output) but no longer selects behaviour per library.
+for the whole run (`LANCZOS_X=1 python3 scripts/ab.py ...`), one process per setting.  A "path.so@NAME=V" library spec (per-library
+environment overrides, rounds 1-2) is refused: it would report two identical runs as two variants.
 """
 import argparse
 import ctypes
@@ -50,7 +50,12 @@ def main():
     handles = []
     for spec in args.libs:
         path, _, envs = spec.partition("@")
-        env = dict(kv.split("=", 1) for kv in envs.split(",")) if envs else {}
+        if envs:
+            sys.exit(f"ab.py: '{spec}': per-library environment overrides no longer select behaviour (the library reads its "
+                     f"environment once per process) -- set {envs} for the whole run, one process per setting")
+        if len(set(os.path.abspath(s) for s in args.libs)) != len(args.libs):
+            sys.exit("ab.py: the same library twice is not an A/B")
+        env = {}
         lib = ctypes.CDLL(os.path.abspath(path))
         lib.lanczos_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
         lib.lanczos_destroy.argtypes = [ctypes.c_void_p]

@@ -60,7 +60,7 @@ def test_validation_codes():
     assert code(in_w=0) == L.ERR_BAD_ARG          # full_TB.h:115-118
     assert code(bps=3) == L.ERR_BAD_ARG
     assert code(sn=0) == L.ERR_BAD_ARG
-    assert code(sn=1, sd=1) == L.OK               # S == 1: one in-place recurrence per column (frames up to 1024 rows run)
+    assert code(sn=1, sd=1) == L.OK               # S == 1: one in-place recurrence per column, any frame height
     assert code(sn=2, sd=3) == L.ERR_UNSUPPORTED  # S < 1: the reference itself writes out of bounds (full_TB.h:85)
     assert code(sn=1, sd=2) == L.ERR_UNSUPPORTED
     # a tampered descriptor (wrong output size) is rejected like a wrong-size image

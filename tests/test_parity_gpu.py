@@ -224,10 +224,19 @@ def test_scales_close_to_one_deep_inplace_prefix(ctx):
         for mode in (L.MODE_EXACT, L.MODE_LSB1):
             _cmp(ctx.resample(img, 4, 4, a, mode), want, mode, f"S=1 {w}x{h}x{c} a={a}")
     assert (_oracle(P.dark_noise(48, 64, 3, seed=5), 1, 1, 3) != P.dark_noise(48, 64, 3, seed=5)).any()   # (the quirk is exercised)
-    with pytest.raises(L.LanczosError) as e:       # ... up to the prefix kernel's depth; S < 1: refused (the reference is out of bounds)
-        ctx.resample(P.noise(1100, 16, 3), 1, 1, 3)
-    assert e.value.code == L.ERR_UNSUPPORTED
-    with pytest.raises(L.LanczosError) as e:
+    # Deeper than the row arrays of k_prefix: the streaming form of the recurrence (k_prefix_stream, rings of 24 rows).  S = 1 at 4K
+    # height and 1025/1024 (K = 2 * 1025 + 1 > the frame height: every output row reads written rows) -- both shapes have
+    # reference builds of their own (oracle/ref_configs.txt, digests in tests/golden/kat_digests.json pin the oracle used here);
+    # plus 16-bit samples, a = 4, and 257/256 with a main kernel below the prefix
+    for (w, h, c, sn, sd, a, gen, dt) in [(24, 2160, 1, 1, 1, 3, P.dark_noise, np.uint8), (64, 1024, 3, 1025, 1024, 3, P.noise, np.uint8),
+                                          (16, 1500, 4, 1, 1, 4, P.noise, np.uint16), (32, 1200, 3, 257, 256, 3, P.dark_noise, np.uint8)]:
+        img = gen(h, w, c, seed=8) if dt == np.uint8 else P.noise(h, w, c, seed=8, dtype=np.uint16)
+        d = L.make_desc(w, h, c, sn, sd, a, img.dtype.itemsize)
+        want = _oracle(img, sn, sd, a)
+        assert want.shape == (d.out_h, d.out_w, c)
+        for mode in (L.MODE_EXACT, L.MODE_LSB1):
+            _cmp(ctx.resample(img, sn, sd, a, mode), want, mode, f"streamed prefix {sn}/{sd} {w}x{h}x{c} a={a} K={L.inplace_rows(d)}")
+    with pytest.raises(L.LanczosError) as e:       # S < 1: refused (the reference itself is out of bounds there)
         ctx.resample(P.noise(16, 16, 3), 3, 4, 3)
     assert e.value.code == L.ERR_UNSUPPORTED
 
