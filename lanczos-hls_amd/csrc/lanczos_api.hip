@@ -338,7 +338,7 @@ int lanczos_strip_input_rows(const lanczos_desc* d, int out_row0, int out_rows, 
         return LANCZOS_ERR_BAD_ARG;
     lz::AxisTaps V;
     if (d->mode == LANCZOS_MODE_HLS) {
-        lz::build_axis_hls(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &V);
+        lz::build_axis_hls(d->in_h, d->out_h, d->scale_n, d->scale_d, d->a, &V, d->reserved[0]);  // (the fixed-point stepper moves the window)
         strip_input_rows(V, d->a, d->in_h, out_row0, out_rows, lz::PrefixInfo(), in_row0, in_rows);
         return LANCZOS_OK;
     }

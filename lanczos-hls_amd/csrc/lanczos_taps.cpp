@@ -62,12 +62,32 @@ void build_axis_hls(int in_n, int out_n, int scale_n, int scale_d, int a, AxisTa
     t->a = a;
     t->first.assign(out_n, 0);
     t->w.assign((size_t)out_n * 2 * a, 0.0);
+    // Where the 2a-row window of output o starts.  Ideal arithmetic: floor(o * D / N) - a + 1.  With BIT_PRECISION > 0 the
+    // reference's own stepper decides (worker.cpp:140, :234): after every output the workers evaluate
+    //     fractional_t(num_el_t(1/SCALE) * (pos + 1)) < fractional_t(1/SCALE)
+    // and shift one input sample in when it holds.  num_el_t = ap_fixed<10+BP,10> cuts 1/SCALE to BP fractional bits (AP_TRN),
+    // the product with the integer counter is exact, fractional_t = ap_ufixed<BP,0> keeps its fractional bits (AP_WRAP) -- so
+    // the window lags wherever Q / 2^BP = trunc(1/SCALE) has drifted below o / SCALE by a whole sample (S = 3: from the first
+    // step on; exact for S = 2, 4; S = 1: fractional_t(1.0) wraps to 0 and the window never moves -- the literal behaviour).
+    long long Q = 0, qcmp = 0, frac = 0;
+    const long long mod = 1ll << (bit_precision > 0 ? bit_precision : 0);
+    if (bit_precision > 0) {
+        Q = (long long)std::floor(std::ldexp(1.0 / ((double)scale_n / scale_d), bit_precision));  // num_el_t(1/SCALE), lanczos.h:112
+        qcmp = Q % mod;                                                                          // fractional_t(1/SCALE)
+    }
+    int steps = 0;
     for (int o = 0; o < out_n; o++) {
-        const int first = (int)(((long long)o * scale_d) / scale_n) - a + 1;
+        const int first = (bit_precision > 0 ? steps : (int)(((long long)o * scale_d) / scale_n)) - a + 1;
+        if (bit_precision > 0) {
+            frac = (frac + Q) % mod;       // fractional bits of num_el_t(1/SCALE) * (o + 1)
+            if (frac < qcmp) steps++;      // step_cond
+        }
         t->first[o] = first;
         for (int k = 0; k < 2 * a; k++) {
             long long idx = (long long)o * scale_d - (long long)(first + k) * scale_n;  // kernel.cpp:56
             if (idx < 0) idx = -idx;
+            // (a lagging window can ask for an entry past the ROM's last one, ROM[a * N] = 0 -- undefined in the reference's C
+            // simulation; here it reads as that last entry)
             double w = idx > (long long)a * scale_n ? 0.0 : hls_rom((int)idx, a, scale_n);
             if (bit_precision > 0) w = std::ldexp(std::floor(std::ldexp(w, bit_precision)), -bit_precision);  // (kernel_t)..., kernel.cpp:42
             t->w[(size_t)o * 2 * a + k] = w;

@@ -32,7 +32,9 @@ double oracle_hls_rom(int k, int a, int scale_n) {
 double oracle_hls_weight(int i, int o, int a, int scale_n, int scale_d) {
     long long k = (long long)o * scale_d - (long long)i * scale_n;
     if (k < 0) k = -k;
-    if (k > (long long)a * scale_n) return 0.0; /* cannot happen inside the window (see header) */
+    if (k > (long long)a * scale_n) return 0.0; /* ideal stepping: cannot happen inside the window.  A window that lags behind
+                                                 * (fixed-point stepper, bp > 0) can ask past the ROM's end -- undefined in the
+                                                 * reference's C simulation; here: the ROM's last entry, 0 */
     return oracle_hls_rom((int)k, a, scale_n);
 }
 
@@ -65,6 +67,31 @@ double oracle_hls_weight_fx(int i, int o, int a, int scale_n, int scale_d, int b
 
 #define HLS_MAX_TAPS 16
 
+/* floor of the window position of every output index.  bp == 0: floor(o * D / N).  bp > 0: the reference's fixed-point stepper
+ * (worker.cpp:140 ColWorkers::exec, :234 RowWorkers::exec): after output o the workers shift one input sample in when
+ *     fractional_t(num_el_t(1/SCALE) * (o + 1)) < fractional_t(1/SCALE)
+ * with num_el_t = ap_fixed<10+BP,10> (1/SCALE cut to BP fractional bits, AP_TRN), an exact product with the integer counter,
+ * and fractional_t = ap_ufixed<BP,0> (the fractional bits, AP_WRAP) -- lanczos.h:74-82, :112. */
+static int* hls_positions(int out_n, int scale_n, int scale_d, int bp) {
+    int* pos = (int*)malloc(sizeof(int) * (size_t)(out_n > 0 ? out_n : 1));
+    if (!pos) return NULL;
+    if (bp <= 0) {
+        for (int o = 0; o < out_n; o++) pos[o] = (int)(((long long)o * scale_d) / scale_n);
+        return pos;
+    }
+    const long long mod = 1ll << bp;
+    const long long Q = (long long)floor(ldexp(1.0 / ((double)scale_n / scale_d), bp));
+    const long long qcmp = Q % mod;
+    long long frac = 0;
+    int steps = 0;
+    for (int o = 0; o < out_n; o++) {
+        pos[o] = steps;
+        frac = (frac + Q) % mod;
+        if (frac < qcmp) steps++;
+    }
+    return pos;
+}
+
 /* one output row: vertical pass of every input column (ColWorkers::exec, worker.cpp:138-155 with compute()
  * worker.cpp:45-78), then the horizontal pass along it (RowWorkers::exec, worker.cpp:225-236 with compute_() :81-115 and
  * clamp_to_byte :118-130). */
@@ -75,10 +102,12 @@ double oracle_hls_weight_fx(int i, int o, int a, int scale_n, int scale_d, int b
         const T* in = (const T*)j->in;                                                                                 \
         T* out = (T*)j->out;                                                                                           \
         double* vrow = (double*)malloc(sizeof(double) * (size_t)W * C);                                                \
+        int* posy = hls_positions(c->out_h, c->scale_n, c->scale_d, bp);                                               \
+        int* posx = hls_positions(c->out_w, c->scale_n, c->scale_d, bp);                                               \
         for (int y = j->y0; y < j->y1; y++) {                                                                          \
             /* window rows floor(y*D/N)-a+1 .. +a; rows < 0 are the zero priming (worker.cpp:176-188), rows > H-1     \
-             * the saturated push (worker.cpp:147-153) */                                                             \
-            const int fy = (int)(((long long)y * c->scale_d) / c->scale_n);                                            \
+             * the saturated push (worker.cpp:147-153); with bp > 0 the window position comes from the fixed-point stepper */ \
+            const int fy = posy[y];                                                                                    \
             double wv[HLS_MAX_TAPS];                                                                                    \
             int rr[HLS_MAX_TAPS];                                                                                       \
             for (int k = 0; k < taps; k++) {                                                                           \
@@ -99,7 +128,7 @@ double oracle_hls_weight_fx(int i, int o, int a, int scale_n, int scale_d, int b
                 vrow[i] = acc < lo ? lo : (acc > hi ? hi : acc);           /* worker.cpp:66-74 */                      \
             }                                                                                                          \
             for (int x = 0; x < c->out_w; x++) {                                                                       \
-                const int fx = (int)(((long long)x * c->scale_d) / c->scale_n);                                        \
+                const int fx = posx[x];                                                                                \
                 double wh[HLS_MAX_TAPS];                                                                                \
                 for (int k = 0; k < taps; k++) wh[k] = oracle_hls_weight_fx(fx - a + 1 + k, x, a, c->scale_n, c->scale_d, bp); \
                 for (int ch = 0; ch < C; ch++) {                                                                       \
@@ -121,6 +150,8 @@ double oracle_hls_weight_fx(int i, int o, int a, int scale_n, int scale_d, int b
             }                                                                                                          \
         }                                                                                                              \
         free(vrow);                                                                                                    \
+        free(posy);                                                                                                    \
+        free(posx);                                                                                                    \
     }
 
 #define ORC_HLS_MIN(a, b) ((a) < (b) ? (a) : (b))
