@@ -56,6 +56,9 @@
 // waves happen to spread evenly over the SIMDs (measured: 3 resident, not the 4 the occupancy API answers).
 // 96 SGPRs -> 7 waves per SIMD: 4 workgroups per CU, +5..9 % (interleaved A/B on one device).
 #define LZ_MARCH_SGPR_ATTR __attribute__((amdgpu_num_sgpr(96)))
+#ifndef LZ_MARCH_MIXV
+#define LZ_MARCH_MIXV 1
+#endif
 
 // Ablation bits (FrameGeom::debug_skip, LANCZOS_DEBUG_SKIP) exist only in builds made with -DLZ_PROFILE_BITS: in the production
 // build every test of them is a compile-time false (the per-row `no_store` test alone was two scalar instructions and a
@@ -682,6 +685,38 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     float vbias = SB == 1 ? (K::SYM ? fc.vbias_rne_p : fc.vbias_rne) : (K::SYM ? fc.bias_p : fc.bias);
     asm volatile("" : "+v"(vbias));
 
+    // MIXV (8-bit, symmetric half-phase weights, EXACT instances): the V window is kept as 16-bit integer lanes instead of floats.
+    // A ring dword splits into its even and odd bytes (two VGPRs per row instead of four floats and the packed copy: 18 registers
+    // fewer through the row loop); a pair sum is ONE v_add_u32 for two samples (<= 510 per lane, no carry); and a 16-bit integer n
+    // IS the f16 denormal n * 2^-24, which v_fma_mix_f32 widens exactly: fma(w * 2^24, n * 2^-24, acc) is the same single
+    // rounding as fmaf(w, (float)n, acc) -- results are bit for bit those of the float window (profiles/round2_probe_mix.txt,
+    // profiles/round4g_*: checked against the float window's output on the GPU).  For the LSB1 instances the float window is 2 %
+    // faster (profiles/round4g_ab_mix_window_and_counted_commit.txt); the EXACT instances, whose exactness tests push the float
+    // version over the 72-register step (9 dwords spilled INSIDE the row loop, each reload a memory round trip in front of the
+    // row's store), run without spills this way.
+    constexpr bool MIXV = LZ_MARCH_MIXV && SB == 1 && K::SYM && EXACT && K::MIN_WAVES > 1;
+    float wmix[A];
+    uint32_t mixmask = 0x00ff00ffu;
+    if (MIXV) {
+#pragma unroll
+        for (int k = 0; k < A; k++) {
+            wmix[k] = wv_[1][k] * 16777216.0f;  // exact
+            asm volatile("" : "+v"(wmix[k]));
+        }
+        asm volatile("" : "+v"(mixmask));
+    }
+    auto mix_lo = [](float w, uint32_t p, float acc) -> float {
+        float r;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(p), "v"(acc));
+        return r;
+    };
+    auto mix_hi = [](float w, uint32_t p, float acc) -> float {
+        float r;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(p), "v"(acc));
+        return r;
+    };
+    uint32_t wev[TAPS], wod[TAPS];   // MIXV: even / odd bytes of the window rows
+
     float win[TAPS][F::VEC];
     uint32_t raw[TAPS];
     auto vpass = [&](int tick) {
@@ -698,6 +733,11 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
         if (m_g + K::MRG <= m_b || m_g >= m_e) return;  // uniform
         const uint32_t* hcol = (const uint32_t*)hbuf + col;
         auto unpack = [&](int slot_i, uint32_t w) {
+            if (MIXV) {
+                wev[slot_i] = w & mixmask;
+                wod[slot_i] = (w >> 8) & mixmask;
+                return;
+            }
             raw[slot_i] = w;
 #pragma unroll
             for (int e = 0; e < F::VEC; e++) {
@@ -706,6 +746,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
             }
         };
         auto ring = [&](int r) { return hcol[K::ring_slot(r - hb) * HP]; };  // H row r of this column
+        auto rawrow = [&](int slot_i) -> uint32_t { return MIXV ? (wev[slot_i] | (wod[slot_i] << 8)) : raw[slot_i]; };
         // rows m_g-a+1 .. m_g+a-1 seed the window; rows before hb were never produced: only read for m < m_b,
         // whose outputs are not stored
 #pragma unroll
@@ -731,7 +772,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                     uint32_t packed;
                     bool undecided = false;
                     if (ph == 0) {
-                        packed = raw[(i + A - 1) % TAPS];
+                        packed = rawrow((i + A - 1) % TAPS);
                         if (EXACT && fc.vlim > 0 && SB == 1 && A >= 3 && fc.tight) {
                             // the H pass's byte-parallel tests on the packed ring dwords: 1 <= v0 <= vlim (and only in
                             // waves that hold such a sample at all) a row two above or below brighter than 2*v0
@@ -739,7 +780,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                             const uint32_t lo = ((t7 + LOW) | x) & ~((t7 + addc) | x) & TOP;
                             if (__any(lo != 0)) {
                                 const uint32_t c2 = (t7 << 1) | TOP;
-                                const uint32_t nm = raw[(i + A - 3) % TAPS], np = raw[(i + A + 1) % TAPS];
+                                const uint32_t nm = rawrow((i + A - 3) % TAPS), np = rawrow((i + A + 1) % TAPS);
                                 const uint32_t pm = (c2 - (nm & LOW)) & ~nm;   // top bit: row m-2 <= 2*v0
                                 const uint32_t pp = (c2 - (np & LOW)) & ~np;   // top bit: row m+2 <= 2*v0
                                 undecided = (lo & ~(pm & pp) & TOP) != 0;
@@ -751,20 +792,36 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                             const float vl = (float)fc.vlim;
 #pragma unroll
                             for (int e = 0; e < F::VEC; e++) {
-                                const float c0 = win[(i + A - 1) % TAPS][e];
+                                auto wf = [&](int slot_i) -> float {   // (MIXV keeps no float window: the sample comes out of the split rows)
+                                    return MIXV ? (float)((rawrow(slot_i) >> (8 * SB * e)) & F::SMASK) : win[slot_i][e];
+                                };
+                                const float c0 = wf((i + A - 1) % TAPS);
                                 bool fl = c0 >= 1.0f && c0 <= vl;
                                 if (A >= 3 && fc.tight)
-                                    fl = fl && (win[(i + A - 3) % TAPS][e] > 2.0f * c0 || win[(i + A + 1) % TAPS][e] > 2.0f * c0);
+                                    fl = fl && (wf((i + A - 3) % TAPS) > 2.0f * c0 || wf((i + A + 1) % TAPS) > 2.0f * c0);
                                 undecided |= fl;
                             }
                         }
                     } else if (LZ_DBG(g, 1024)) {  // profiling bit 1024: computed rows are copies too (loads + stores, no V arithmetic)
-                        packed = raw[(i + A - 1) % TAPS];
+                        packed = rawrow((i + A - 1) % TAPS);
                     } else {
                         packed = 0;
                         float accs[F::VEC];
+                        if (MIXV) {
 #pragma unroll
-                        for (int e = 0; e < F::VEC; e++) {
+                            for (int e = 0; e < 4; e++) accs[e] = vbias;
+#pragma unroll
+                            for (int k = 0; k < A; k++) {  // outside in, as the float chain
+                                const uint32_t pe = wev[(i + k) % TAPS] + wev[(i + TAPS - 1 - k) % TAPS];
+                                const uint32_t po = wod[(i + k) % TAPS] + wod[(i + TAPS - 1 - k) % TAPS];
+                                accs[0] = mix_lo(wmix[k], pe, accs[0]);
+                                accs[1] = mix_lo(wmix[k], po, accs[1]);
+                                accs[2] = mix_hi(wmix[k], pe, accs[2]);
+                                accs[3] = mix_hi(wmix[k], po, accs[3]);
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < F::VEC && !MIXV; e++) {
                             float acc = vbias;
                             if (K::SYM) {
 #pragma unroll
@@ -831,6 +888,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                 redo_mask &= redo_mask - 1;
                 const int y = m_g * S + r, m = y / S;
                 if (!(m >= m_b && m < m_e && y >= y_lo && y < y_hi) || no_store) continue;
+                // (the phase weights out of LDS instead of the table row: measured, no faster -- profiles/round4n_*)
                 const double* wvd = t.v_w + (size_t)y * TAPS;
                 uint32_t rw[TAPS];
 #pragma unroll
