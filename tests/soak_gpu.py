@@ -24,7 +24,7 @@ import patterns as P  # noqa: E402
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     u16_share = float(sys.argv[2]) if len(sys.argv) > 2 else 0.2
-    rng = np.random.default_rng(20261005)  # (round 3: 4x added, every (C, S, a) now has a specialised instance)
+    rng = np.random.default_rng(20261006)  # (round 4: deep in-place prefixes added; EXACT instances of 2x a=3 run the 16-bit-lane window)
     ctx = L.Context(0)
     gens = [P.noise, P.dark_noise, P.gradient_noise, lambda h, w, c, seed=0: P.blocks(h, w, c)]
     t0 = time.time()
@@ -38,10 +38,13 @@ def main():
         # widths: mostly multiples that keep rows 16-byte multiples (marching kernel), sometimes ragged
         w = int(rng.integers(3, 60)) * 16 if rng.random() < 0.7 else int(rng.integers(40, 700))
         h = int(rng.integers(24, 260))
-        if (w * sn) % sd or (h * sn) % sd:
+        if rng.random() < 0.04:   # round 4: in-place prefixes deeper than the row arrays of k_prefix (k_prefix_stream), S = 1 included
+            sn, sd = [(1, 1), (33, 32), (129, 128), (1025, 1024)][int(rng.integers(0, 4))]
+            w, h = int(rng.integers(1, 5)) * 16, int(rng.integers(300, 1400))
+        elif (w * sn) % sd or (h * sn) % sd:
             continue
         gen = gens[int(rng.integers(0, len(gens)))]
-        cfg = O.cfg(w, h, w * sn // sd, h * sn // sd, c, a, sn, sd)
+        cfg = O.cfg(w, h, w * sn // sd, h * sn // sd, c, a, sn, sd)   # (floor, as lanczos_desc_init)
         if u16_share > 0 and rng.random() < u16_share:  # 16-bit samples: the build's generalisation (clamp 65535)
             gen = P.noise
             img = P.noise(h, w, c, seed=int(rng.integers(0, 1 << 30)), dtype=np.uint16)
