@@ -406,17 +406,19 @@ def main():
             # LANCZOS_MODE_EXACT -- what lanczos_u8() and the literal lanczos(stream_t, stream_t) drop-in always run: the same
             # frames, the same launch shape, bit-identical results, whole-step device time
             exact = {}
-            desc_keep = wl.desc
-            wl.desc = L.make_desc(cfg[0], cfg[1], cfg[2], cfg[4], cfg[5], cfg[6], cfg[3], L.MODE_EXACT,
-                                  out_row0=getattr(wl, "row0", 0) if wl.desc is not wl.full else 0,
-                                  out_rows=wl.rows if wl.desc is not wl.full else 0)
+            desc_keep, full_keep = wl.desc, wl.full
+            if wl.desc is wl.full:
+                wl.desc = wl.full = L.make_desc(cfg[0], cfg[1], cfg[2], cfg[4], cfg[5], cfg[6], cfg[3], L.MODE_EXACT)
+            else:   # a row strip of the frame (--config c5 at N > 1)
+                wl.desc = L.make_desc(cfg[0], cfg[1], cfg[2], cfg[4], cfg[5], cfg[6], cfg[3], L.MODE_EXACT,
+                                      out_row0=wl.row0, out_rows=wl.rows)
             for pat in ("gradient", "noise"):
                 wl.refill(pat, 4321 + (rank if shard == "frames" else 0))
                 settle(wl, min(args.settle_s, 0.1))
                 s_o = sorted(device_batch_time(torch, wl, max(10, args.steps // 2)) for _ in range(3))[1]
                 exact[pat] = {"step_us": round(s_o * 1e6, 2),
                               "roofline_frac": round(wl.alg_bytes / s_o / 1e9 / HBM_PEAK_GBS, 4)}
-            wl.desc = desc_keep
+            wl.desc, wl.full = desc_keep, full_keep
             extra["other_modes"] = {"exact": exact}
         wl.refill(args.pattern, seed)
         wl.step()

@@ -29,6 +29,15 @@
 // else -- takes 176 us per 32 frames of config 2 (0.707 of 8 TB/s; reads and writes do not overlap in the DRAM); the kernel
 // takes 203-212 us, of which its arithmetic adds 15-25 us on top of its own memory skeleton.
 //
+// Round 4 tried the three structural levers that were left, each an interleaved A/B with bit-identical (or, for the first, +-1 LSB)
+// output; the patches and their measurements are under profiles/ (experiments/round4_*.patch, round4[c-r]_*.txt):
+//   * the V pass on the matrix cores (ds_read_b64_tr_b8 of the row-major ring -> f16 MFMA with hi + lo weights -> permlane
+//     transposes -> 16-byte stores): parity-green, 220-264 us against 215 -- per useful output its v_perm conversions, byte
+//     converts and MFMA issue slots cost what the FMA chains cost, and its natural store shape (16 rows x 16 bytes) runs at 1.2 TB/s;
+//   * input rows requested a whole tick ahead, made affordable by that V pass (no 30-register window): 228 against 217 us;
+//     requested in front of the V stores and committed behind them with a counted s_waitcnt vmcnt(12): 238 against 220 us;
+//   * the V window as 16-bit integer lanes (v_fma_mix_f32 on f16 denormals): 65 instead of 72 VGPRs, bit-identical, 219.5
+//     against 214.9 us in LSB1 mode -- kept only for the EXACT instances, whose float window spilled inside the row loop.
 // Around the tick loop (all measured, profiles/README.md):
 //   * the table deals whole frames to every XCD (neighbouring strips share an L2: every input line is fetched from HBM once)
 //     and gives the workgroup slots a CU fills first -- whose waves are older and win the SIMD arbitration -- more rows;
