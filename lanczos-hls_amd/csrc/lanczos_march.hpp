@@ -68,6 +68,9 @@
 #ifndef LZ_MARCH_MIXV
 #define LZ_MARCH_MIXV 1
 #endif
+#ifndef LZ_MARCH_MIXV_LSB1   // A/B builds only: the 16-bit-lane window in the LSB1 instances too (2 % slower there, see vpass)
+#define LZ_MARCH_MIXV_LSB1 0
+#endif
 
 // Ablation bits (FrameGeom::debug_skip, LANCZOS_DEBUG_SKIP) exist only in builds made with -DLZ_PROFILE_BITS: in the production
 // build every test of them is a compile-time false (the per-row `no_store` test alone was two scalar instructions and a
@@ -703,7 +706,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     // faster (profiles/round4g_ab_mix_window_and_counted_commit.txt); the EXACT instances, whose exactness tests push the float
     // version over the 72-register step (9 dwords spilled INSIDE the row loop, each reload a memory round trip in front of the
     // row's store), run without spills this way.
-    constexpr bool MIXV = LZ_MARCH_MIXV && SB == 1 && K::SYM && EXACT && K::MIN_WAVES > 1;
+    constexpr bool MIXV = LZ_MARCH_MIXV && SB == 1 && K::SYM && (EXACT || LZ_MARCH_MIXV_LSB1) && K::MIN_WAVES > 1;
     float wmix[A];
     uint32_t mixmask = 0x00ff00ffu;
     if (MIXV) {
