@@ -82,10 +82,13 @@ struct RootOps {
     std::vector<uint8_t*> recv_base;
     int group_start() { return (int)rccl->GroupStart(); }
     int group_end() { return (int)rccl->GroupEnd(); }
+    bool has(int rank) const { return rank >= 0 && (size_t)rank < comms->size() && (size_t)rank < send_base.size(); }
     int send(int rank, size_t off, size_t bytes, int peer) {
+        if (!has(rank)) return (int)ncclInvalidArgument;   // a list that names a rank this process does not hold
         return (int)rccl->Send(send_base[rank] + off, bytes, ncclUint8, peer, (*comms)[rank], (*streams)[rank]);
     }
     int recv(int rank, size_t off, size_t bytes, int peer) {
+        if (!has(rank)) return (int)ncclInvalidArgument;
         return (int)rccl->Recv(recv_base[rank] + off, bytes, ncclUint8, peer, (*comms)[rank], (*streams)[rank]);
     }
 };

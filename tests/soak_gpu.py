@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/soak_gpu.py [seconds] [share of 16-bit cases] -- randomized parity soak on a GPU box (test infrastructure, not collected by pytest).
+"""tests/soak_gpu.py [seconds] [share of 16-bit cases] [seed] -- randomized parity soak on a GPU box (test infrastructure, not collected by pytest).
 
 Random shapes / channel counts / scales / a / input generators, both parity modes, compared with the CPU oracle
 (oracle/, the restated reference software path).  Prints one line per failure and a summary; exit code 1 on any
@@ -24,7 +24,7 @@ import patterns as P  # noqa: E402
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     u16_share = float(sys.argv[2]) if len(sys.argv) > 2 else 0.2
-    rng = np.random.default_rng(20261006)  # (round 4: deep in-place prefixes added; EXACT instances of 2x a=3 run the 16-bit-lane window)
+    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 20261006)  # (round 4: deep in-place prefixes added; EXACT instances of 2x a=3 run the 16-bit-lane window)
     ctx = L.Context(0)
     gens = [P.noise, P.dark_noise, P.gradient_noise, lambda h, w, c, seed=0: P.blocks(h, w, c)]
     t0 = time.time()
