@@ -92,6 +92,9 @@ struct lanczos_ctx {
 static constexpr size_t kStampBytes = 16384 * 8 * 6 * 8;
 #endif
 static constexpr size_t kMaxPlans = 32;
+#ifndef LZ_SPLIT_RULE
+#define LZ_SPLIT_RULE 1
+#endif
 
 namespace {
 
@@ -702,12 +705,17 @@ static int resample_device_locked(lanczos_ctx* ctx, const lanczos_desc* d, const
         } else {
             lz::FrameGeom gm = g;
             if (!in_split) {   // (with timing on, every sub-launch commits its own event triple: what is timed is what is shipped)
-                // A batch of twice the kernel's preferred size or more goes out as several launches of that size: one resident
-                // round of workgroups with two chunks per (strip, frame) pair is the fastest shape this kernel has.
+                // A batch of twice the kernel's preferred size or more goes out as launches of that size (two chunks per (strip,
+                // frame) pair, rank-aware shares: the fastest shape this kernel has) followed by the rest.  The four-workgroups-per-CU
+                // instances already split at one and a half times that size: their one-workgroup-per-slot table degrades quickly
+                // (config 2, 48 frames: 400 us in one launch, 333 us as 32 + 16; 40 frames: 289 us either way), that of the
+                // two-workgroups-per-CU instances does not (config 3, 40 frames: 251 us in one launch, 272 us as 24 + 16) --
+                // profiles/round4y_ab_oversized_batch_split_rule.txt.
                 bool dummy = false;
                 e = lz::march_launch(*d, gm, p->dev, p->fast, stream, &dummy, &ctx->wg_tabs, /*query_only=*/true);
                 const int pf = ctx->wg_tabs.pref_frames;
-                if (e == hipSuccess && pf >= 8 && frames >= 2 * pf) {
+                const bool split = frames >= 2 * pf || (LZ_SPLIT_RULE && ctx->wg_tabs.wg_per_cu >= 4 && frames >= pf + pf / 2);
+                if (e == hipSuccess && pf >= 8 && split) {
                     for (int f0 = 0; f0 < frames; f0 += pf) {
                         const int nf = frames - f0 < pf ? frames - f0 : pf;
                         rc = resample_device_locked(ctx, d, (const uint8_t*)d_in + (size_t)f0 * g.in_frame_stride,

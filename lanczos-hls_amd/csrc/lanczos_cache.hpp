@@ -116,6 +116,11 @@ struct WgTabCacheT {
     // shares (config 2: 32 frames = 960 workgroups on 1 024 slots).  Larger batches are faster as several launches of this size
     // (64 frames: 2 x 207 us against 502 us in one launch, profiles/round3g_bench_default.json); 0: no preference
     int pref_frames = 0;
+    // the largest batch that still is ONE resident round of two chunks per (strip, frame) pair (config 2: 34 frames): beyond it a
+    // single launch falls back to one workgroup per slot with shares across pairs (48 frames: 399 us) and is slower than a launch of
+    // pref_frames followed by the rest (32 + 16 frames: 207 + 113 us)
+    int max_one_round_frames = 0;
+    int wg_per_cu = 0;   // resident marching workgroups per CU of the instance the last query was about
 
     Item* find(const long long (&key)[8]) {
         for (size_t i = 0; i < items.size(); i++)

@@ -1306,6 +1306,8 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     }
     {
         int pf = (nb * cus) / (2 * strips);
+        cache->max_one_round_frames = pf;
+        cache->wg_per_cu = nb;
         while (pf > 0 && (2 * strips * pf) % 16 != 0) pf--;   // every XCD gets whole pairs of chunks (march_build_table: balanced)
         cache->pref_frames = pf;
     }

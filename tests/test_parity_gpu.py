@@ -287,8 +287,9 @@ def test_batch_of_frames(ctx):
 
 
 def test_oversized_batch_goes_out_as_several_launches(ctx):
-    """A device batch of twice the marching kernel's preferred size or more (1920-wide RGB8 2x: 32 frames) is split into
-    launches of that size inside lanczos_resample_device; 70 frames = 32 + 32 + 6, every frame against the oracle's frame
+    """A device batch of twice the marching kernel's preferred size or more (1920-wide RGB8 2x: 32 frames; one and a half times
+    for the four-workgroups-per-CU instances) is split into launches of that size inside lanczos_resample_device; 70 frames =
+    32 + 32 + 6, every frame against the oracle's frame
     (the frames are short, the width is config 2's: 15 strips)."""
     import torch
     w, h, f = 1920, 20, 70
@@ -304,8 +305,10 @@ def test_oversized_batch_goes_out_as_several_launches(ctx):
     got = y.cpu().numpy()
     for i in (0, 1, 31, 32, 33, 63, 64, 69):
         assert np.array_equal(got[i], _oracle(frames[i], 2, 1, 3)), i
-    one = ctx.resample(frames[:40], 2, 1, 3, L.MODE_EXACT)       # below twice the preferred size: one launch, same bytes
+    one = ctx.resample(frames[:40], 2, 1, 3, L.MODE_EXACT)       # below one and a half times the preferred size: one launch, same bytes
     assert np.array_equal(one, got[:40])
+    mid = ctx.resample(frames[:50], 2, 1, 3, L.MODE_EXACT)       # 48 <= frames < 64: 32 + 18 (round 4: the four-per-CU instances split earlier)
+    assert np.array_equal(mid, got[:50])
 
 
 def test_bounded_caches_survive_many_shapes():
