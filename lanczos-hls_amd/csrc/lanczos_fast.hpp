@@ -51,6 +51,11 @@ struct FastConsts {
                                     //    are < 2^-55, so neighbours <= 2*v0 prove that v0 stays (see fast_prepare)
     int tight2;                     // 1: additionally the +-1 taps are positive and twice the +-2 taps and half the spacing
                                     //    below v0 is >= 3.4 v0 |L(2)|: the second-stage filter of k_march applies
+    // 16-bit samples at S = 2, marching kernel: the split-weight chain (lanczos_taps.hpp: split_chain_prepare).  [phase][tap];
+    // only [1][0..a-1] are used (paired chain).
+    float wsh[kFastMaxS][kMaxTaps], wsl[kFastMaxS][kMaxTaps];
+    float bias_s, near2_s;          // eps of that chain (start value of its lo half) and 2 * eps
+    int split_ok;                   // 1: the fields above are valid (always for the instantiated 16-bit 2x configurations)
 };
 
 // per-configuration tile shape: MR input rows advanced per tile, NGRP vertical thread groups in the V pass
@@ -555,6 +560,30 @@ inline bool fast_prepare(const lanczos_desc& d, const AxisTaps& H, const AxisTap
         fc->bias_p = (float)eps_p;
         fc->vbias_rne_p = (float)eps_p - 0.5f;
         fc->near2_p = (float)(2.0 * eps_p) * 1.0001f;
+    }
+    {   // split-weight chain of the marching kernel's 16-bit 2x instances (paired chain: taps 0..a-1)
+        fc->split_ok = 0;
+        fc->bias_s = fc->near2_s = 0.0f;
+        for (int ph = 0; ph < kFastMaxS; ph++)
+            for (int k = 0; k < kMaxTaps; k++) fc->wsh[ph][k] = fc->wsl[ph][k] = 0.0f;
+        if (d.bytes_per_sample == 2 && S == 2) {
+            const double per_index = 4.0 * 2.220446049250313e-16 * (H.out_n > V.out_n ? H.out_n : V.out_n) * maxv * taps;
+            const double* w1 = &ax->w[(size_t)(S * a + 1) * taps];
+            int order[kMaxTaps];
+            for (int k = 0; k < a; k++) order[k] = k;
+            SplitChain sc;
+            const bool ok = split_chain_prepare(w1, order, a, 2.0 * maxv, &sc);
+            double partner = 0;  // the exact chain uses w[2a-1-k] for the partner sample: the same number up to its last bits
+            for (int k = 0; k < a; k++) partner += std::fabs(w1[k] - w1[taps - 1 - k]) * maxv;
+            const double eps_s = sc.eps + 1.02 * partner + per_index;
+            if (ok && eps_s < 0.005) {
+                for (int k = 0; k < a; k++) fc->wsh[1][k] = sc.wh[k], fc->wsl[1][k] = sc.wl[k];
+                fc->bias_s = (float)eps_s;
+                fc->near2_s = (float)(2.0 * eps_s) * 1.0001f;
+                fc->split_ok = 1;
+            }
+            if (!fc->split_ok) return false;  // (cannot happen for a = 2..4: the kernels' 16-bit 2x instances rely on it)
+        }
     }
     fc->vlim = integer_phase_flip_limit(fc->wi, a, (int)maxv);
     if (fc->vlim >= (d.bytes_per_sample == 1 ? 126 : 32766)) return false;  // SWAR test needs vlim < half range

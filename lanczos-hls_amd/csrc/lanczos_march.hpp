@@ -68,6 +68,12 @@
 #ifndef LZ_MARCH_MIXV
 #define LZ_MARCH_MIXV 1
 #endif
+#ifndef LZ_MARCH_SPLIT       // 16-bit samples, EXACT instances: split-weight chains (0: A/B builds only -- the single f32 chain)
+#define LZ_MARCH_SPLIT 1
+#endif
+#ifndef LZ_MARCH_SPLIT_LSB1  // A/B builds only: the split-weight H chain in the LSB1 instances too (see MarchCfg::SPLIT)
+#define LZ_MARCH_SPLIT_LSB1 0
+#endif
 #ifndef LZ_MARCH_MIXV_LSB1   // A/B builds only: the 16-bit-lane window in the LSB1 instances too (2 % slower there, see vpass)
 #define LZ_MARCH_MIXV_LSB1 0
 #endif
@@ -160,7 +166,16 @@ struct MarchCfg {
     // near-integer flags per SAMPLE instead of per unit: with 16-bit samples the f32 window is 2 eps ~ 0.03 (eps scales
     // with the sample range), a quarter of all units hold a flagged sample, and redoing every sample of such a unit in
     // f64 was a third of config 5's time; 8-bit configurations flag one sample in 10^4 and keep the cheaper unit flag
-    static constexpr bool NEAR_PER_SAMPLE = SB == 2;
+    // 16-bit samples, S = 2: every weight split into an exactly-summing coarse part and a small remainder (lanczos_taps.hpp:
+    // split_chain_prepare): the near-integer window shrinks from 2 eps = 0.025 to 5e-4 and the redo rate from one sample in 40 to
+    // one in 2 000, so the H flag goes back to one per UNIT (a max and a min per sample instead of a compare, a select and an or
+    // into a 64-bit mask) -- at +a fmafs and +5 epilogue instructions per computed sample.  Used by the EXACT instances, whose V
+    // pass found an undecided sample in nearly every row of 128 and redid it in f64: config 5, 8 frames, gradient 2 021 -> 987 us,
+    // noise 3 443 -> 2 366, blocks 1 904 -> 1 285, bit-identical.  The LSB1 instances (V pass untested) keep the single chain: with
+    // the split H chain gradient 613.5 -> 623.5 us, blocks 620 -> 613, noise 885 -> 780 (profiles/round4z_ab_split_weight_chain_*).
+    // (S = 3, whose chains are 2a fmafs long, does not fit its registers: 61 -> 168 VGPRs and spills.)
+    static constexpr bool SPLIT = LZ_MARCH_SPLIT && SB == 2 && S == 2;   // (the kernel uses it where EXACT || LZ_MARCH_SPLIT_LSB1)
+    static constexpr bool NEAR_PER_SAMPLE = SB == 2;                     // (... and the per-unit flag with it)
     // Register budget (2nd launch bound = waves per SIMD the compiler must leave room for).  6-wave workgroups land 2+2+1+1 on
     // the four SIMDs from a varying start, so four of them only fit reliably when a SIMD may hold SEVEN waves: 72 VGPRs.
     // Configurations the compiler leaves just above that step are told to stay under it -- the EXACT variants too, whose 9
@@ -189,6 +204,8 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
     constexpr int TAPS = K::TAPS, SB = K::SB;
+    constexpr bool SPLIT = MarchCfg<T, C, S, A>::SPLIT && (EXACT || LZ_MARCH_SPLIT_LSB1);
+    constexpr bool NEAR_PER_SAMPLE = MarchCfg<T, C, S, A>::NEAR_PER_SAMPLE && !SPLIT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* hbuf = smem + K::LDS_TIN;
     const int tid = threadIdx.x;
@@ -384,6 +401,20 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
             asm volatile("" : "+v"(wv_[ph][k]));
         }
     auto wv = [&](int ph, int k) -> float { return (K::MIRROR && ph == 2) ? wv_[1][TAPS - 1 - k] : wv_[ph][k]; };
+    float wsh_[NPHW][TAPS], wsl_[NPHW][TAPS];  // SPLIT: coarse / remainder halves of the H weights
+    float sbias = fc.bias_s;
+    if (SPLIT) {
+#pragma unroll
+        for (int ph = 1; ph < NPHW; ph++)
+#pragma unroll
+            for (int k = 0; k < (K::SYM ? A : TAPS); k++) {
+                wsh_[ph][k] = fc.wsh[ph][k], wsl_[ph][k] = fc.wsl[ph][k];
+                asm volatile("" : "+v"(wsh_[ph][k]), "+v"(wsl_[ph][k]));
+            }
+        asm volatile("" : "+v"(sbias));
+    }
+    auto wsh = [&](int ph, int k) -> float { return (K::MIRROR && ph == 2) ? wsh_[1][TAPS - 1 - k] : wsh_[ph][k]; };
+    auto wsl = [&](int ph, int k) -> float { return (K::MIRROR && ph == 2) ? wsl_[1][TAPS - 1 - k] : wsl_[ph][k]; };
     constexpr uint32_t HALF = SB == 1 ? 0x80u : 0x8000u;
     const uint32_t addc1 = (uint32_t)fc.vlim < HALF - 1 ? HALF - 1 - (uint32_t)fc.vlim : 0;
     // the chain bias and the SWAR masks live in VGPRs for the same reason (a literal is a constant-bus read too)
@@ -482,6 +513,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
             }
             float dmin = 1.0f;
             uint32_t dminu = 0x7f800000u;  // SB == 1: smallest fract(acc) - 0.5 seen, compared as unsigned bit patterns
+            unsigned pend[K::P * S];       // SPLIT, even C: the even channel's sample waits for its dword partner
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 float fch[F::WIN_PX];
@@ -496,6 +528,35 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                 for (int q = 0; q < K::P * S; q++) {
                     const int p = q / S, ph = q % S;
                     if (ph == 0) continue;
+                    const int o = q * C + c;
+                    if (SPLIT) {
+                        // hi: exact (every product and partial sum is an integer multiple of 2^-q below 2^24).  lo: an f32 chain
+                        // of numbers 2^-(q+1) as large, started at fract(hi) + eps.  floor(hi) + floor(lo) is then floor(sum + eps')
+                        // with eps' in (0, 2 eps); fract(lo) < 2 eps = undecided
+                        float ah = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < A; k++) ah = __builtin_fmaf(wsh(ph, k), fch[p + k] + fch[p + TAPS - 1 - k], ah);
+                        const float fh = __builtin_amdgcn_fractf(ah);   // exact: a multiple of 2^-q in [0, 1)
+                        float al = fh + sbias;
+#pragma unroll
+                        for (int k = 0; k < A; k++) al = __builtin_fmaf(wsl(ph, k), fch[p + k] + fch[p + TAPS - 1 - k], al);
+                        const float jt = __builtin_floorf(al);
+                        const float r = (ah - fh) + jt;             // exact: integers below 2^24
+                        // (al - floor(al) is exact wherever it is small.  A sum below 1 stores 0 whatever it is: r <= 0 puts 1 - r >= 1
+                        // in the minimum instead -- black regions and empty channels, whose sums are exactly 0 and whose lo halves are
+                        // exactly eps, must not flag)
+                        dmin = __builtin_fminf(dmin, __builtin_fmaxf(al - jt, 1.0f - r));
+                        unsigned uv;                                // the hardware convert saturates (negative -> 0); a C++ cast of a
+                        asm("v_cvt_u32_f32 %0, %1" : "=v"(uv) : "v"(r));  // negative float is undefined, hence the instruction itself
+                        if (C % 2 == 0) {
+                            // the two halves of an output dword are the same pixel's channels c, c + 1: one saturating pack
+                            if (c % 2 == 0) pend[q] = uv;
+                            else ow[o / 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(pend[q], uv));
+                        } else {
+                            ow[o / 2] |= (uv < 65535u ? uv : 65535u) << (16 * (o % 2));
+                        }
+                        continue;
+                    }
                     float acc = hbias;
                     if (K::SYM) {
 #pragma unroll
@@ -508,7 +569,6 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                             acc = __builtin_fmaf(wv(ph, k), fch[p + k], acc);
                         }
                     }
-                    const int o = q * C + c;
                     if (K::RNE_H) {
                         // acc = sum + (eps - 0.5) + chain error, |chain error| < eps: the saturating round-to-nearest-even
                         // byte convert is floor(sum + eps') with eps' in (0, 2 eps) -- the reference's truncating store --
@@ -528,7 +588,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         // sums are exactly 0, must not look "within eps of an integer"); the float -> u32 convert truncates
                         // and an unsigned min saturates: 2.5 slow-class ops per sample instead of 4
                         const float m = __builtin_fmaxf(acc, 0.5f);
-                        if (K::NEAR_PER_SAMPLE) nearmask |= (unsigned long long)(__builtin_amdgcn_fractf(m) < near2) << o;
+                        if (NEAR_PER_SAMPLE) nearmask |= (unsigned long long)(__builtin_amdgcn_fractf(m) < near2) << o;
                         else dmin = __builtin_fminf(dmin, __builtin_amdgcn_fractf(m));
                         unsigned uv = (unsigned)m;                      // v_cvt_u32_f32: truncation
                         uv = uv < 65535u ? uv : 65535u;
@@ -537,7 +597,8 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            near = K::NEAR_PER_SAMPLE ? nearmask != 0 : (K::RNE_H ? dminu < __builtin_bit_cast(uint32_t, near2) : dmin < near2);
+            near = NEAR_PER_SAMPLE ? nearmask != 0 : (K::RNE_H ? dminu < __builtin_bit_cast(uint32_t, near2) : dmin < near2);
+            if (SPLIT) near = dmin < fc.near2_s;
             // widest aligned LDS stores the unit allows
             if (F::UNIT_OUT_DW % 2 == 0) {
 #pragma unroll
@@ -588,6 +649,9 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                 }
             }
         }
+#ifdef LZ_MARCH_DIAG_NONEAR   // timing diagnostics only (results are then wrong): no near-integer flags
+        near = false, nearmask = 0;
+#endif
         if (LZ_DBG(g, 32 | 256 | 512)) {  // profiling bits: 32 no flags at all, 256 no near flags, 512 no integer flags
             if (LZ_DBG(g, 32 | 512)) im = 0;
             if (LZ_DBG(g, 32 | 256)) near = false, nearmask = 0;
@@ -661,7 +725,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                     if (cnt > K::WLW - K::WL_ROUND || (e == F::VEC && cnt > 0)) flush();
                 }
             }
-            if (K::NEAR_PER_SAMPLE) {
+            if (NEAR_PER_SAMPLE) {
                 if (__any(near)) {  // every flagged non-integer-phase sample
 #pragma unroll 1
                     for (int o = 0; o < F::UNIT_OUT_S; o++) {
@@ -819,6 +883,31 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                     } else {
                         packed = 0;
                         float accs[F::VEC];
+                        if (SPLIT && EXACT) {
+                            // 16-bit samples: the H pass's split-weight chain (exact coarse half, small remainder started at
+                            // fract(hi) + eps): the undecided window is 5e-4 instead of 0.025, where nearly every row of 128
+                            // samples held an undecided one and was redone in f64
+                            float ftmin = 1.0f;
+                            unsigned uvv[F::VEC];
+#pragma unroll
+                            for (int e = 0; e < F::VEC; e++) {
+                                float ah = 0.0f;
+#pragma unroll
+                                for (int k = 0; k < A; k++)
+                                    ah = __builtin_fmaf(wsh(ph, k), win[(i + k) % TAPS][e] + win[(i + TAPS - 1 - k) % TAPS][e], ah);
+                                const float fh = __builtin_amdgcn_fractf(ah);
+                                float al = fh + sbias;
+#pragma unroll
+                                for (int k = 0; k < A; k++)
+                                    al = __builtin_fmaf(wsl(ph, k), win[(i + k) % TAPS][e] + win[(i + TAPS - 1 - k) % TAPS][e], al);
+                                const float jt = __builtin_floorf(al);
+                                const float r = (ah - fh) + jt;
+                                ftmin = __builtin_fminf(ftmin, __builtin_fmaxf(al - jt, 1.0f - r));   // (r <= 0: stores 0 whatever the sum)
+                                asm("v_cvt_u32_f32 %0, %1" : "=v"(uvv[e]) : "v"(r));   // saturating: negative -> 0
+                            }
+                            packed = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(uvv[0], uvv[F::VEC - 1]));
+                            undecided = ftmin < fc.near2_s;
+                        } else {
                         if (MIXV) {
 #pragma unroll
                             for (int e = 0; e < 4; e++) accs[e] = vbias;
@@ -876,6 +965,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                                 packed |= (unsigned)fl << (8 * SB * e);
                             }
                         }
+                        }  // !(SPLIT && EXACT)
                     }
                     bool redo_row = false;
                     if (EXACT) {

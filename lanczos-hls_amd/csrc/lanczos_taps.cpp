@@ -143,8 +143,12 @@ int validate(const lanczos_desc* d) {
 }
 
 double f32_chain_error_bound_ordered(const double* w, const int* order, int n, double maxv) {
+    return f32_chain_error_bound_from(w, order, n, maxv, 0.5 + 1e-3);
+}
+
+double f32_chain_error_bound_from(const double* w, const int* order, int n, double maxv, double start) {
     const double u = std::ldexp(1.0, -24);  // f32 unit roundoff
-    double P = 0.5 + 1e-3, err = 0, wq = 0;
+    double P = start, err = 0, wq = 0;
     for (int j = 0; j < n; j++) {
         const int k = order[j];
         const double wf = (double)(float)w[k];
@@ -169,6 +173,41 @@ double f32_chain_error_bound(const double* w, int ntaps, double maxv) {
         wq += std::fabs(wf - w[k]) * maxv;
     }
     return 1.02 * (err + wq);  // 2 % slack
+}
+
+bool split_chain_prepare(const double* w, const int* order, int n, double maxs, SplitChain* sc) {
+    // Largest q for which every prefix of the hi chain is an integer multiple of 2^-q below 2^(24-q): with samples in [0, maxs]
+    // a prefix lies between -(sum of the negative wh so far) * maxs and +(sum of the positive ones) * maxs.
+    const double u = std::ldexp(1.0, -24);
+    for (int q = 12; q >= 3; q--) {
+        const double sc2 = std::ldexp(1.0, q);
+        double wh[kMaxTaps], pos = 0, neg = 0;
+        bool ok = true;
+        for (int j = 0; j < n && ok; j++) {
+            const int k = order[j];
+            wh[k] = std::nearbyint(w[k] * sc2) / sc2;
+            (wh[k] > 0 ? pos : neg) += std::fabs(wh[k]);
+            ok = (pos > neg ? pos : neg) * maxs * sc2 <= 16777216.0;
+        }
+        if (!ok) continue;
+        double wl[kMaxTaps], sum_wl = 0;
+        for (int k = 0; k < kMaxTaps; k++) sc->wh[k] = sc->wl[k] = 0.0f, wl[k] = 0.0;
+        for (int j = 0; j < n; j++) {
+            const int k = order[j];
+            wl[k] = w[k] - wh[k];                       // exact: both are doubles of the same magnitude class, |wl| <= 2^-(q+1)
+            sc->wh[k] = (float)wh[k];                   // exact: <= 13 significant bits
+            sc->wl[k] = (float)wl[k];
+            sum_wl += std::fabs((double)sc->wl[k]);
+        }
+        // the lo chain starts at fl(fract(hi) + eps) -- below 1.01, one rounding of its own -- and is compared with the real
+        // fract(hi) + eps + sum of wl * v; weight quantisation included
+        (void)sum_wl;
+        const double start = 1.01;
+        sc->q = q;
+        sc->eps = f32_chain_error_bound_from(wl, order, n, maxs, start) + 1.02 * u * start;
+        return sc->eps < 0.005;  // (the caller's eps must stay below the 0.01 that `start` allows for)
+    }
+    return false;
 }
 
 bool integer_phase_tight(const double* wi, int a, double maxv) {

@@ -56,6 +56,22 @@ constexpr int f32_tap_order(int step, int ntaps) { return (step & 1) ? ntaps - 1
 double f32_chain_error_bound(const double* w, int ntaps, double maxv);
 // The same bound for a chain that adds w[order[0]], w[order[1]], ... w[order[n-1]] in that order (n taps used)
 double f32_chain_error_bound_ordered(const double* w, const int* order, int n, double maxv);
+// ... with a start value of magnitude <= start instead of 0.5
+double f32_chain_error_bound_from(const double* w, const int* order, int n, double maxv, double start);
+
+// Split-weight chain for 16-bit samples, where one f32 accumulator cannot hold 16 integer bits and a useful fraction (its
+// error bound, 0.013 for Lanczos-4, puts one sample in 40 on the exact-redo list).  Every weight is split w = wh + wl with wh a
+// multiple of 2^-q chosen so that wh * v and ALL partial sums of the hi chain are exact in f32 (integers * 2^-q below 2^24);
+// wl = w - wh (|wl| <= 2^-(q+1)) runs through an ordinary f32 chain whose magnitudes, and with them its rounding errors, are
+// 2^-(q+1) of the plain chain's.  The kernel starts the lo chain at fract(hi) + eps and stores floor(hi) + floor(lo).
+//   w[k], k = order[0..n-1]: the taps in the order the chain adds them; maxs: largest (pair) sample.
+//   eps: rigorous bound on |lo - eps - (real sum - floor(hi))| (the per-index / mirrored-weight terms are the caller's).
+struct SplitChain {
+    int q = 0;
+    float wh[kMaxTaps], wl[kMaxTaps];  // indexed by tap k
+    double eps = 0;
+};
+bool split_chain_prepare(const double* w, const int* order, int n, double maxs, SplitChain* sc);
 
 // Largest centre sample v0 for which the integer-phase double chain can still end below v0
 // (SURVEY.md Q4); every v0 above it provably comes out unchanged.  wi[k] = L(a-1-k), k = 0..2a-1.

@@ -142,6 +142,33 @@ def test_every_integer_scale_instance(ctx, mode):
                 assert ctx.last_kernel() == L.KERNEL_FAST, (dt.__name__, c, s, a, w)
 
 
+def test_sixteen_bit_exact_mode_split_weight_chains(ctx):
+    """The EXACT instances of the 16-bit 2x kernels run split-weight chains in both passes (lanczos_march.hpp: SPLIT -- an exactly
+    summing coarse half plus a small remainder; tests/test_split_chain.py proves the arithmetic on the CPU).  Content chosen for
+    what that arithmetic has to get right: empty channels and black regions (sums exactly 0: exempt from the undecided flag),
+    saturated edges (overshoot above 65535 and below 0: the saturating converts), flat areas (every sample of a row on the same
+    fraction), a smooth ramp with noise, plain noise.  Bit-identical to the checker; 16-bit: parity unpinned by the reference."""
+    h, w = 70, 320
+    yy, xx = np.mgrid[0:h, 0:w]
+    for c in (3, 4):
+        cc = np.arange(c)[None, None, :]
+        blocks = (((yy // 16 + xx // 16)[..., None] + cc) % 5 * 15000).astype(np.uint16)           # one channel in five is 0
+        edges = np.where(((xx // 24 + yy // 10) % 2 == 0)[..., None], 65535, 0).astype(np.uint16).repeat(c, 2)
+        edges[..., 0] = 0                                                                          # an empty channel
+        ramp = np.clip(((yy * 900 + xx * 190)[..., None] + P.noise(h, w, c, seed=5, dtype=np.uint16) // 64), 0, 65535).astype(np.uint16)
+        flat = np.full((h, w, c), 40000, np.uint16)
+        flat[:, w // 2:] = 12345
+        for a in (3, 4):
+            for name, img in (("blocks", blocks), ("edges", edges), ("ramp", ramp), ("flat", flat),
+                              ("noise", P.noise(h, w, c, seed=6, dtype=np.uint16))):
+                img = np.ascontiguousarray(img)
+                want = _oracle(img, 2, 1, a)
+                for mode in (L.MODE_EXACT, L.MODE_LSB1):
+                    got = ctx.resample(img, 2, 1, a, mode)
+                    _cmp(got, want, mode, f"uint16 c={c} a={a} {name}")
+                    assert ctx.last_kernel() == L.KERNEL_FAST
+
+
 RATIONAL_SHAPES = [
     # (in_w, in_h, channels, sn, sd, a) -- output rows are dword multiples: served by k_rat
     (300, 200, 3, 4, 3, 3), (256, 120, 3, 3, 2, 3), (400, 90, 4, 3, 2, 2), (128, 77, 1, 5, 2, 4), (240, 131, 3, 5, 3, 3),
