@@ -513,7 +513,7 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
             }
             float dmin = 1.0f;
             uint32_t dminu = 0x7f800000u;  // SB == 1: smallest fract(acc) - 0.5 seen, compared as unsigned bit patterns
-            unsigned pend[K::P * S];       // SPLIT, even C: the even channel's sample waits for its dword partner
+            unsigned pend[K::P * S];       // 16-bit samples, even C: the even channel's sample waits for its dword partner
 #pragma unroll
             for (int c = 0; c < C; c++) {
                 float fch[F::WIN_PX];
@@ -591,11 +591,22 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         if (NEAR_PER_SAMPLE) nearmask |= (unsigned long long)(__builtin_amdgcn_fractf(m) < near2) << o;
                         else dmin = __builtin_fminf(dmin, __builtin_amdgcn_fractf(m));
                         unsigned uv = (unsigned)m;                      // v_cvt_u32_f32: truncation
-                        uv = uv < 65535u ? uv : 65535u;
-                        ow[o / 2] |= uv << (16 * (o % 2));
+                        if (C % 2 == 0) {
+                            // the two halves of an output dword are the same pixel's channels c, c + 1 (an even channel waits for
+                            // its partner): one saturating pack instead of two unsigned minima, a shift and two ors
+                            if (c % 2 == 0) pend[q] = uv;
+                            else ow[o / 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_u16(pend[q], uv));
+                        } else {
+                            uv = uv < 65535u ? uv : 65535u;
+                            ow[o / 2] |= uv << (16 * (o % 2));
+                        }
                     }
                 }
+#ifndef LZ_MARCH_DIAG_NOFENCE
                 __builtin_amdgcn_sched_barrier(0);
+#else
+                if (SB == 1) __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             near = NEAR_PER_SAMPLE ? nearmask != 0 : (K::RNE_H ? dminu < __builtin_bit_cast(uint32_t, near2) : dmin < near2);
             if (SPLIT) near = dmin < fc.near2_s;

@@ -24,7 +24,7 @@ import patterns as P  # noqa: E402
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     u16_share = float(sys.argv[2]) if len(sys.argv) > 2 else 0.2
-    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 20261006)  # (round 4: deep in-place prefixes added; EXACT instances of 2x a=3 run the 16-bit-lane window)
+    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 20261006)  # (round 4: deep in-place prefixes added; EXACT instances of 2x a=3 run the 16-bit-lane window; 16-bit: structured content for the split-weight chains)
     ctx = L.Context(0)
     gens = [P.noise, P.dark_noise, P.gradient_noise, lambda h, w, c, seed=0: P.blocks(h, w, c)]
     t0 = time.time()
@@ -48,8 +48,19 @@ def main():
         if u16_share > 0 and rng.random() < u16_share:  # 16-bit samples: the build's generalisation (clamp 65535)
             gen = P.noise
             img = P.noise(h, w, c, seed=int(rng.integers(0, 1 << 30)), dtype=np.uint16)
-            if rng.random() < 0.5:
+            kind = int(rng.integers(0, 6))
+            if kind < 2:
                 img = (img >> int(rng.integers(4, 12))).astype(np.uint16)  # darker: integer-phase candidates
+            elif kind == 2:   # a smooth ramp with small noise (the split-weight chains' everyday case)
+                yy, xx = np.mgrid[0:h, 0:w]
+                img = np.clip((yy * int(rng.integers(0, 400)) + xx * int(rng.integers(0, 300)))[..., None] + (img >> 10), 0, 65535).astype(np.uint16)
+            elif kind == 3:   # flat blocks, one channel in five empty; saturated blocks beside black ones
+                yy, xx = np.mgrid[0:h, 0:w]
+                lev = np.array([0, 15000, 30000, 65535, 40000], np.uint16)
+                img = lev[((yy // 16 + xx // 16)[..., None] + np.arange(c)[None, None, :]) % 5]
+            elif kind == 4:   # noise with an empty channel and a saturated one
+                img[..., 0] = 0
+                img[..., c - 1] = 65535
             want = O.expected_hwc_u16(cfg, img, threads=16)
         else:
             img = gen(h, w, c, seed=int(rng.integers(0, 1 << 30)))
