@@ -602,11 +602,9 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
                         }
                     }
                 }
-#ifndef LZ_MARCH_DIAG_NOFENCE
+                // (16-bit instances, whose residency LDS limits, without this fence: 624.9 against 624.5 us on config 5 -- that
+                // configuration is not VALU-bound; profiles/round4z_ab_split_weight_chain_config5.txt)
                 __builtin_amdgcn_sched_barrier(0);
-#else
-                if (SB == 1) __builtin_amdgcn_sched_barrier(0);
-#endif
             }
             near = NEAR_PER_SAMPLE ? nearmask != 0 : (K::RNE_H ? dminu < __builtin_bit_cast(uint32_t, near2) : dmin < near2);
             if (SPLIT) near = dmin < fc.near2_s;
