@@ -1005,12 +1005,29 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
 #pragma unroll
                 for (int k = 0; k < TAPS; k++) rw[k] = ring(m - A + 1 + k);
                 uint32_t packed = 0;
+                if (r % S == 0 && fc.skip_last) {
+                    // an integer-phase row (on noise: nearly every one of them holds a candidate): the H fix-up's short chain -- the
+                    // centre weight is exactly 1 (the product is the sample itself), the ~1e-33 tap at x - i = -a is inert
+                    // (FastConsts::skip_last), the weights are the same for every row (LDS) -- 4 multiplies and 5 adds instead of 6 + 6
+                    const double* xw = (const double*)(smem + K::LDS_TIN + K::LDS_HBUF + K::LDS_WL);
 #pragma unroll 1
-                for (int e = 0; e < F::VEC; e++) {
-                    double sum = 0;
+                    for (int e = 0; e < F::VEC; e++) {
+                        double sum = 0;
 #pragma unroll
-                    for (int k = 0; k < TAPS; k++) sum += (double)((rw[k] >> (8 * SB * e)) & F::SMASK) * wvd[k];
-                    packed |= (unsigned)store_convert<T>(sum) << (8 * SB * e);
+                        for (int k = 0; k < TAPS - 1; k++) {
+                            const double v = (double)((rw[k] >> (8 * SB * e)) & F::SMASK);
+                            sum += k == A - 1 ? v : v * xw[k];
+                        }
+                        packed |= (unsigned)store_convert<T>(sum) << (8 * SB * e);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int e = 0; e < F::VEC; e++) {
+                        double sum = 0;
+#pragma unroll
+                        for (int k = 0; k < TAPS; k++) sum += (double)((rw[k] >> (8 * SB * e)) & F::SMASK) * wvd[k];
+                        packed |= (unsigned)store_convert<T>(sum) << (8 * SB * e);
+                    }
                 }
                 __builtin_amdgcn_raw_buffer_store_b32(packed, orsrc, col_b, (y - g.out_row0) * g.out_pitch, LZ_STORE_AUX);
             }
