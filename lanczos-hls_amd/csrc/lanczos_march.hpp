@@ -200,7 +200,7 @@ struct MarchCfg {
 // no separate k_prefix launch).  That variant rebuilds its per-lane indices every tick to stay inside the register
 // budget; the batch variant (RIDE = false) holds them in registers, which is 2-3 % faster when the chip is full.
 template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
-__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::MIN_WAVES)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
+__device__ __forceinline__ void march_body(const FrameGeom& g, const TapTables& t, const FastConsts& fc) {
     using K = MarchCfg<T, C, S, A>;
     using F = typename K::F;
     constexpr int TAPS = K::TAPS, SB = K::SB;
@@ -1114,6 +1114,38 @@ __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::
     }
 }
 
+// The kernel proper, twice: with the 96-SGPR cap (7 waves per SIMD: what four 6-wave workgroups per CU need) and without it.
+// Instances that cannot hold 7 waves per SIMD anyway (their VGPRs or their LDS decide) gain nothing from the cap and, where the
+// row loop is long, pay for it with scalar registers spilled to VGPR lanes INSIDE the loop: the EXACT 8-bit RGB 3x instances
+// carried ~500 v_readlane_b32 (config 3, EXACT: 547 -> ... us, profiles/round4z_ab_exact_3x_sgpr_cap.txt).
+template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
+__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::MIN_WAVES)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
+    march_body<T, C, S, A, EXACT, STAMP, RIDE>(g, t, fc);
+}
+template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
+__global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::MIN_WAVES)) void k_march_ws(FrameGeom g, TapTables t, FastConsts fc) {
+    march_body<T, C, S, A, EXACT, STAMP, RIDE>(g, t, fc);
+}
+// which of the two an instance runs
+template <typename T, int C, int S, int A, bool EXACT>
+constexpr bool march_wide_sgpr() {
+#ifdef LZ_MARCH_NO_WIDE_SGPR   // A/B builds only
+    return false;
+#else
+    return EXACT && ((sizeof(T) == 1 && C == 3 && S == 3) || sizeof(T) == 2);
+#endif
+}
+template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
+inline const void* march_kernel_fn() {
+    if constexpr (march_wide_sgpr<T, C, S, A, EXACT>()) return (const void*)k_march_ws<T, C, S, A, EXACT, STAMP, RIDE>;
+    else return (const void*)k_march<T, C, S, A, EXACT, STAMP, RIDE>;
+}
+template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
+inline void march_kernel_launch(dim3 grid, dim3 block, size_t lds, hipStream_t stream, const FrameGeom& g, const TapTables& t, const FastConsts& fc) {
+    if constexpr (march_wide_sgpr<T, C, S, A, EXACT>()) hipLaunchKernelGGL((k_march_ws<T, C, S, A, EXACT, STAMP, RIDE>), grid, block, lds, stream, g, t, fc);
+    else hipLaunchKernelGGL((k_march<T, C, S, A, EXACT, STAMP, RIDE>), grid, block, lds, stream, g, t, fc);
+}
+
 // the marching kernel moves whole 16-byte chunks: rows, frames and the base must be 16-byte multiples
 inline bool march_supports(const FrameGeom& g) {
     return g.in_pitch % 16 == 0 && (((uintptr_t)g.in) & 15) == 0 && (g.in_frame_stride & 15) == 0 &&
@@ -1398,8 +1430,8 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
             cus_of[dev] = 256;
         if (slots[exact][dev] == 0) {
             int n = 0;
-            hipError_t e = exact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_march<T, C, S, A, true>, K::NT, K::LDS_BYTES)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_march<T, C, S, A, false>, K::NT, K::LDS_BYTES);
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, exact ? march_kernel_fn<T, C, S, A, true>() : march_kernel_fn<T, C, S, A, false>(),
+                                                                        K::NT, K::LDS_BYTES);
             if (e != hipSuccess || n < 1) n = 1;
             // (With the 96-SGPR cap the API's answer holds.  At the compiler's own ~105 SGPRs a CU admitted one 6-wave workgroup
             // fewer than the API said -- waves land unevenly on the SIMDs and the SGPR file caps waves per SIMD,
@@ -1411,8 +1443,8 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
         }
         for (int ride = 0; ride < 2; ride++) {
             if (attr_done[exact][ride][dev]) continue;
-            const void* fn = exact ? (ride ? (const void*)k_march<T, C, S, A, true, false, true> : (const void*)k_march<T, C, S, A, true>)
-                                   : (ride ? (const void*)k_march<T, C, S, A, false, false, true> : (const void*)k_march<T, C, S, A, false>);
+            const void* fn = exact ? (ride ? march_kernel_fn<T, C, S, A, true, false, true>() : march_kernel_fn<T, C, S, A, true>())
+                                   : (ride ? march_kernel_fn<T, C, S, A, false, false, true>() : march_kernel_fn<T, C, S, A, false>());
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES);
             if (e != hipSuccess) return e;
             attr_done[exact][ride][dev] = true;
@@ -1465,8 +1497,8 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
     note_stream(item->streams, stream);
     dim3 grid(g.n_main + g.prefix_blocks_per_frame * g.frames);
     if (*prefix_fused) {
-        if (exact) hipLaunchKernelGGL((k_march<T, C, S, A, true, false, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
-        else hipLaunchKernelGGL((k_march<T, C, S, A, false, false, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
+        if (exact) march_kernel_launch<T, C, S, A, true, false, true>(grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
+        else march_kernel_launch<T, C, S, A, false, false, true>(grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
         return hipGetLastError();
     }
 #ifdef LZ_PROFILE_BITS
@@ -1476,8 +1508,8 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
         return hipGetLastError();
     }
 #endif
-    if (exact) hipLaunchKernelGGL((k_march<T, C, S, A, true>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
-    else hipLaunchKernelGGL((k_march<T, C, S, A, false>), grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
+    if (exact) march_kernel_launch<T, C, S, A, true>(grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
+    else march_kernel_launch<T, C, S, A, false>(grid, dim3(K::NT), K::LDS_BYTES, stream, g, t, fc);
     return hipGetLastError();
 }
 
