@@ -1117,7 +1117,7 @@ __device__ __forceinline__ void march_body(const FrameGeom& g, const TapTables& 
 // The kernel proper, twice: with the 96-SGPR cap (7 waves per SIMD: what four 6-wave workgroups per CU need) and without it.
 // Instances that cannot hold 7 waves per SIMD anyway (their VGPRs or their LDS decide) gain nothing from the cap and, where the
 // row loop is long, pay for it with scalar registers spilled to VGPR lanes INSIDE the loop: the EXACT 8-bit RGB 3x instances
-// carried ~500 v_readlane_b32 (config 3, EXACT: 547 -> ... us, profiles/round4z_ab_exact_3x_sgpr_cap.txt).
+// carried ~500 v_readlane_b32 (config 3, EXACT: 547 -> 474 us; profiles/round4z_ab_sgpr_cap_lifted.txt).
 template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
 __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::MIN_WAVES)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
     march_body<T, C, S, A, EXACT, STAMP, RIDE>(g, t, fc);
@@ -1126,13 +1126,17 @@ template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool 
 __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::MIN_WAVES)) void k_march_ws(FrameGeom g, TapTables t, FastConsts fc) {
     march_body<T, C, S, A, EXACT, STAMP, RIDE>(g, t, fc);
 }
-// which of the two an instance runs
+// which of the two an instance runs.  Workgroups land on the four SIMDs of a CU unevenly (a 6-wave workgroup as 2+2+1+1 from
+// a varying start), so a CU that is to hold W waves needs room for ceil(W / 4) + 1 on every SIMD; without the cap (106 SGPRs)
+// a SIMD holds 6.  Instances whose LDS footprint keeps a CU at W <= 20 waves therefore lose nothing by running uncapped, and
+// the cap costs them spilled scalars: config 3 (3 x 5 waves) 206.4 -> 195.7 us, config 5 (2 x 8 waves) 604.8 -> 599.3 us.
 template <typename T, int C, int S, int A, bool EXACT>
 constexpr bool march_wide_sgpr() {
 #ifdef LZ_MARCH_NO_WIDE_SGPR   // A/B builds only
     return false;
 #else
-    return EXACT && ((sizeof(T) == 1 && C == 3 && S == 3) || sizeof(T) == 2);
+    using K = MarchCfg<T, C, S, A>;
+    return (160 * 1024 / K::LDS_BYTES) * K::NWAVES <= 20;
 #endif
 }
 template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
