@@ -180,7 +180,13 @@ struct MarchCfg {
     // the four SIMDs from a varying start, so four of them only fit reliably when a SIMD may hold SEVEN waves: 72 VGPRs.
     // Configurations the compiler leaves just above that step are told to stay under it -- the EXACT variants too, whose 9
     // spilled dwords sit on the cold f64 redo path (84 VGPRs, 388 us -> 72 VGPRs, 330 us per 32 frames of config 2).
-    static constexpr int MIN_WAVES = (SB == 1 && S == 2 && A == 3 && NT == 384) ? 7 : 1;
+    // The 8-bit RGB 3x a = 3 kernels (config 3: three 6-wave workgroups per CU by LDS) are told to leave room for SIX waves per SIMD
+    // (80 VGPRs): the EXACT instance took 85 and lost its third workgroup per CU (472 -> 334 us per 32 frames, 7 spilled dwords
+    // included); the LSB1 instance, at 75, gains the hoisted lane constants below (194.1 -> 192.5 us).  profiles/round4z_ab_config3_*
+#ifndef LZ_MARCH_C3_MIN_WAVES
+#define LZ_MARCH_C3_MIN_WAVES 6
+#endif
+    static constexpr int MIN_WAVES = (SB == 1 && S == 2 && A == 3 && NT == 384) ? 7 : ((SB == 1 && S == 3 && C == 3 && A == 3) ? LZ_MARCH_C3_MIN_WAVES : 1);
     // Per-lane address parts of the input loads and of the H unit held in registers for a whole segment (a tick adds one scalar)
     // instead of being rebuilt every tick from the thread id (~35 VALU instructions, six of them quarter-rate multiplies).
     // Worth 1.5-2 % where the three registers fit under the occupancy step (config 2: 218 -> 214.5 us, profiles/
@@ -1437,6 +1443,29 @@ inline hipError_t march_launch_t(const lanczos_desc& d, const FrameGeom& g_in, c
             hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, exact ? march_kernel_fn<T, C, S, A, true>() : march_kernel_fn<T, C, S, A, false>(),
                                                                         K::NT, K::LDS_BYTES);
             if (e != hipSuccess || n < 1) n = 1;
+            {   // The API counts waves as if they spread evenly over the four SIMDs.  They do not: a workgroup whose wave count is
+                // not a multiple of 4 lands unevenly from a varying start (6 waves: 2+2+1+1), and n workgroups only fit reliably
+                // when every SIMD has room for ceil(n * waves / 4) + 1.  Where the instance's registers do not leave that room the
+                // last workgroup per CU does not become resident, the table would be laid out for slots that do not exist and the
+                // launch would run a part-empty second round (the EXACT 8-bit RGB 3x instance: 85 VGPRs = 5 waves per SIMD, three
+                // 6-wave workgroups need 6: 472 us per 32 frames of config 3, 334 once it was told to stay at 80 VGPRs).
+                hipFuncAttributes fa;
+                const void* fn = exact ? march_kernel_fn<T, C, S, A, true>() : march_kernel_fn<T, C, S, A, false>();
+                if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0 && fa.numRegs <= 512) {
+                    const int cap_v = 512 / ((fa.numRegs + 7) & ~7) < 8 ? 512 / ((fa.numRegs + 7) & ~7) : 8;
+                    const bool wide = exact ? march_wide_sgpr<T, C, S, A, true>() : march_wide_sgpr<T, C, S, A, false>();
+                    const int cap_s = wide ? 6 : 7;   // 106 / 96 SGPRs (MI355X_MICROARCH.md, "Residency")
+                    const int cap = cap_v < cap_s ? cap_v : cap_s;
+                    auto need = [](int nn) { return K::NWAVES % 4 == 0 ? nn * K::NWAVES / 4 : (nn * K::NWAVES + 3) / 4 + 1; };
+                    const int n_api = n;
+                    while (n > 1 && need(n) > cap) n--;
+                    if (env().verbose)
+                        fprintf(stderr, "lanczos: k_march<%d B,%d ch,x%d,a=%d,%s> %d VGPRs: %d waves per SIMD, %d workgroups/CU by the API, %d resident\n",
+                                (int)sizeof(T), C, S, A, exact ? "exact" : "lsb1", fa.numRegs, cap, n_api, n);
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
             // (With the 96-SGPR cap the API's answer holds.  At the compiler's own ~105 SGPRs a CU admitted one 6-wave workgroup
             // fewer than the API said -- waves land unevenly on the SIMDs and the SGPR file caps waves per SIMD,
             // MI355X_MICROARCH.md "Residency" -- and the grid's second round ran part-empty.)
