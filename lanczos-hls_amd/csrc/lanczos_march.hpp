@@ -182,16 +182,35 @@ struct MarchCfg {
     // spilled dwords sit on the cold f64 redo path (84 VGPRs, 388 us -> 72 VGPRs, 330 us per 32 frames of config 2).
     // The 8-bit RGB 3x a = 3 kernels (config 3: three 6-wave workgroups per CU by LDS) are told to leave room for SIX waves per SIMD
     // (80 VGPRs): the EXACT instance took 85 and lost its third workgroup per CU (472 -> 334 us per 32 frames, 7 spilled dwords
-    // included); the LSB1 instance, at 75, gains the hoisted lane constants below (194.1 -> 192.5 us).  profiles/round4z_ab_config3_*
+    // included); the LSB1 instance, at 75, gains the hoisted lane constants below (194.1 -> 192.5 us).  profiles/round4z_ab_config3_registers_and_residency.txt
 #ifndef LZ_MARCH_C3_MIN_WAVES
 #define LZ_MARCH_C3_MIN_WAVES 6
 #endif
-    static constexpr int MIN_WAVES = (SB == 1 && S == 2 && A == 3 && NT == 384) ? 7 : ((SB == 1 && S == 3 && C == 3 && A == 3) ? LZ_MARCH_C3_MIN_WAVES : 1);
+#ifndef LZ_MARCH_AUTO_MIN_WAVES   // A/B builds only (1): EVERY instance is told to leave room for the workgroups its LDS footprint allows
+#define LZ_MARCH_AUTO_MIN_WAVES 0
+#endif
+    // waves per SIMD that nb resident workgroups need (uneven landing: see march_launch_t), and the largest nb the LDS allows
+    // whose need the register files can meet at all (8 waves per SIMD; 7 under the 96-SGPR cap, 6 without it)
+    static constexpr int need_waves(int nb) { return NWAVES % 4 == 0 ? nb * NWAVES / 4 : (nb * NWAVES + 3) / 4 + 1; }
+    static constexpr int auto_min_waves() {
+        const int lim = (160 * 1024 / LDS_BYTES) * NWAVES <= 20 ? 6 : 7;
+        int nb = 160 * 1024 / LDS_BYTES;
+        while (nb > 1 && need_waves(nb) > lim) nb--;
+        return need_waves(nb) <= lim ? need_waves(nb) : 1;
+    }
+    static constexpr bool TUNED_C2 = SB == 1 && S == 2 && A == 3 && NT == 384;   // 4 x 6 waves per CU: 7 per SIMD
+    static constexpr bool TUNED_C3 = SB == 1 && S == 3 && C == 3 && A >= 3;       // 3 x 6 waves per CU: 6 per SIMD (a = 2 fits by itself)
+    // The instances whose own register count left a CU short of the workgroups its LDS admits, and that are faster when told to
+    // make room (sweep of all 35 instances in both modes, profiles/round4z_sweep_min_waves.txt: -6 ... -25 %; the others move
+    // by +-2 % or lose -- 8-bit RGB 4x a = 3 EXACT +12 % -- and keep the compiler's choice)
+    static constexpr bool AUTO_OK = SB == 1 && ((S == 2 && A == 4 && C != 4) || (S == 3 && C == 4 && A == 3) || (S == 3 && C == 1 && A >= 3) ||
+                                                (S == 4 && C == 1 && A == 3) || (S == 4 && C == 3 && A == 2));
+    static constexpr int MIN_WAVES = TUNED_C2 ? 7 : (TUNED_C3 ? LZ_MARCH_C3_MIN_WAVES : ((LZ_MARCH_AUTO_MIN_WAVES || AUTO_OK) ? auto_min_waves() : 1));
     // Per-lane address parts of the input loads and of the H unit held in registers for a whole segment (a tick adds one scalar)
     // instead of being rebuilt every tick from the thread id (~35 VALU instructions, six of them quarter-rate multiplies).
     // Worth 1.5-2 % where the three registers fit under the occupancy step (config 2: 218 -> 214.5 us, profiles/
-    // round3k_ab_hoisted_lane_constants.txt); where they do not, the rebuild stays (config 3: 75 -> 85 VGPRs, 217 -> 309 us).
-    static constexpr bool HOIST = MIN_WAVES > 1;
+    // round3k_ab_hoisted_lane_constants.txt; config 3 once its kernels were told to stay at 80 VGPRs: 194.1 -> 192.5 us).
+    static constexpr bool HOIST = (TUNED_C2 || TUNED_C3) && MIN_WAVES > 1;
     static_assert(MS % NGRP == 0, "V groups split a tick evenly");
     static_assert(MRG * S <= 64, "the EXACT-mode redo mask has one bit per output row of a V group");
     static_assert(NGRP == 1 || NVT_PAD % 64 == 0, "V groups must be whole waves");
@@ -1123,7 +1142,7 @@ __device__ __forceinline__ void march_body(const FrameGeom& g, const TapTables& 
 // The kernel proper, twice: with the 96-SGPR cap (7 waves per SIMD: what four 6-wave workgroups per CU need) and without it.
 // Instances that cannot hold 7 waves per SIMD anyway (their VGPRs or their LDS decide) gain nothing from the cap and, where the
 // row loop is long, pay for it with scalar registers spilled to VGPR lanes INSIDE the loop: the EXACT 8-bit RGB 3x instances
-// carried ~500 v_readlane_b32 (config 3, EXACT: 547 -> 474 us; profiles/round4z_ab_sgpr_cap_lifted.txt).
+// carried ~500 v_readlane_b32 (config 3, EXACT: 547 -> 474 us; profiles/round4z_ab_config3_registers_and_residency.txt).
 template <typename T, int C, int S, int A, bool EXACT, bool STAMP = false, bool RIDE = false>
 __global__ __launch_bounds__((MarchCfg<T, C, S, A>::NT), (MarchCfg<T, C, S, A>::MIN_WAVES)) LZ_MARCH_SGPR_ATTR void k_march(FrameGeom g, TapTables t, FastConsts fc) {
     march_body<T, C, S, A, EXACT, STAMP, RIDE>(g, t, fc);
